@@ -1,0 +1,85 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X render library (librt_amd.so, built from ray-tracer_amd/csrc/).
+ *
+ * This is the drop-in boundary for the reference's render hot path: everything behind
+ *     int RayTracer::Render(Image &im, double fSamplesPerPixel)        RayTracer2020.cpp:33-38
+ * (SamplingTile::Render -> CastFunction -> Camera::Emit -> RayTracer::VisualRay -> Solid::Intersect ...).
+ * Plain pointers and sizes only; the caller owns every buffer it passes.  One rt_scene handle
+ * belongs to one GPU (the device current when it was uploaded); handles are thread-compatible,
+ * not thread-safe.  All functions return 0 on success, a negative RT_ERR_* code otherwise, and
+ * rt_last_error() describes the last failure on the calling thread.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include "rt_scene_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,        /* malformed scene / arguments */
+    RT_ERR_UNSUPPORTED = -2,    /* node / texture / sampler without a device path yet */
+    RT_ERR_DEVICE = -3,         /* HIP error */
+    RT_ERR_HIT_OVERFLOW = -4,   /* a ray's hit list exceeded the per-ray arena; the image is not valid */
+    RT_ERR_NOMEM = -5
+};
+
+typedef struct rt_scene rt_scene;
+
+const char *rt_last_error(void);
+
+/* Flatten + upload a scene to the current HIP device.  Replaces the implicit "scene is a pointer
+   graph reachable from RayTracer" of the reference (RayTracer2020.h:188-202); the description must
+   be the graph as it stands after psModel->Optimize() (TestScene.cpp:1614). */
+int  rt_scene_upload(const RtSceneDesc *desc, rt_scene **out);
+void rt_scene_free(rt_scene *s);
+
+/* RayTracer::Render (RayTracer2020.cpp:33-38; SamplingTile::Render, RayTracer2020.h:182).
+   planes: HOST float[3][height][width], layout i + W*(j + H*k) (Image.h:235), linear RGB.
+   stats->samples is the reference's return value. */
+int  rt_render(rt_scene *s, const RtRenderDesc *rd, float *planes, RtStats *stats);
+
+/* Same, writing into DEVICE memory (hipMalloc'ed float[3][H][W]) on `hip_stream` (a hipStream_t, 0 =
+   default stream) without the final device->host copy: what bench.py times (inputs resident in HBM)
+   and what a multi-GPU caller gathers with RCCL. */
+int  rt_render_device(rt_scene *s, const RtRenderDesc *rd, float *planes_dev, RtStats *stats, void *hip_stream);
+
+/* ---- parity probes: the same device code paths, exposed per stage (host buffers) ------------- */
+
+/* Sample generation of the scene's sampling tile (Sampling.cpp:335-346 / 498-517): samples
+   [first, first+n) in the reference's loop order.  out8: vx, vy (normalised image position) and
+   g_uCamera, g_vCamera, g_uLight, g_vLight, g_uMicroFacet, g_vMicroFacet.  out_xy: position in the
+   supersampled image (FASTBLUE) or pixel centre (TEST).  Returns total sample count in *total. */
+int  rt_probe_samples(rt_scene *s, const RtRenderDesc *rd, int64_t first, int64_t n, double *out8, double *out_xy, int64_t *total);
+
+/* Camera::Emit (Cameras.h:8-67) for n positions v2[2n] with aux dims aux6[6n] (may be null). */
+int  rt_probe_camera(rt_scene *s, int n, const double *v2, const double *aux6, double *org3, double *dir3);
+
+/* psModel->Intersect(ray) (RayTracer2020.h:72) for n rays: the full hit list, up to max_hits records
+   per ray: t, normal (object space; after TransformNormals, Shade.cpp:264-284, when transform != 0),
+   ids (RtNode.id) of the primitive, the material (-1 vacuum, -2 neutronium) and the surface
+   (-3 default matte, -9 none). */
+int  rt_probe_intersect(rt_scene *s, int n, const double *org3, const double *dir3, const double *aux6, int max_hits, int transform,
+                        int *out_count, double *out_t, double *out_n3, int *out_leaf, int *out_mat, int *out_surf);
+
+/* RayTracer::VisualRay (Shade.cpp:401-520) for n rays: 10-band radiance per ray. */
+int  rt_probe_radiance(rt_scene *s, int n, const double *org3, const double *dir3, const double *aux6, float *out_spec10);
+
+/* Per-sample RGB of a render (what is splatted), in loop order: float[3*samples]. */
+int  rt_probe_sample_rgb(rt_scene *s, const RtRenderDesc *rd, float *out_rgb, int64_t max_samples, RtStats *stats);
+
+/* BuildQuasiIndex (Patterns.cpp:1723-1736), RandomUnsigned (MonteCarlo.h:17-27): host-side integer helpers. */
+void rt_build_quasi_index(int *out, int prime, int n);
+void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);
+
+/* Tunables (no counterpart in the reference).  name: "hit_arena" (hits per ray, default 48),
+   "chunk_samples" (samples per wavefront pass), "bvh" (0/1). */
+int  rt_set_option(const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

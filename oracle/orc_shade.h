@@ -1,0 +1,52 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.h).
+ * Scene container + shading entry points (restating Shade.cpp, Lights.h/.cpp, Cameras.h).
+ */
+#pragma once
+#include "orc_solids.h"
+
+namespace orc {
+
+struct Light {
+    int  type, no_shadow;
+    V3   org, vA, vB;
+    Spec flux;
+};
+
+struct Scene {
+    std::vector<Node*> nodes;       /* index == RtSceneDesc node index */
+    Node   *root;
+    std::vector<Light> lights;
+    bool    has_ambient;
+    Spec    ambient;
+    RtCamera cam;
+    int     sampler_type, venera;
+    std::vector<int> qi2, qi3;
+    double  aux_init[6];
+    Scene() : root(0), has_ambient(false), sampler_type(0), venera(0) {}
+    ~Scene() { for (size_t i = 0; i < nodes.size(); i++) delete nodes[i]; }
+};
+
+/* spectral constants the shader needs (RadiometryColor.cpp:616-790, :26-37, :336-372), read from tables.bin */
+struct Tables {
+    bool  loaded;
+    Spec  metal_n[11], metal_k[11];     /* indexed by MAT_COPPER..MAT_TITANIUM */
+    float spec2rgb[NSPEC][3];
+    Spec  chan[3];                      /* g_sRedChannel, g_sGrnChannel, g_sBluChannel */
+    std::vector<double> blue;           /* g_rgvBlueNoise, 1600 x 2 */
+    Tables() : loaded(false) {}
+};
+extern Tables g_t;
+
+float band_noise(const float *p, int ndim);
+float gradient_band_noise(float *g, const float *p, int ndim);
+void  apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx);
+void  transform_normals_export(Hit &h, const Ctx &cx);   /* TransformNormals, Shade.cpp:264-284 */
+
+Ray  camera_emit(const RtCamera &c, double vx, double vy, const Ctx &cx);
+Spec visual_ray(Scene &s, const Ray &ray, Ctx &cx);
+Spec light_ray(Scene &s, const Ray &ray, const Light &l, Ctx &cx);
+Rgb  spectrum_srgb(const Spec &s);
+Rgb  spectrum_vrgb(const Spec &s);
+
+} // namespace orc

@@ -1,0 +1,189 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.h).
+ * CPU restatement of the lattice-noise core (Texture.cpp:11-191) and the bump-map call-outs built on
+ * it (TextureMaps.cpp:189-369).  All noise arithmetic is float, hashes are 32-bit integer.
+ */
+#include "orc_shade.h"
+
+namespace orc {
+
+/* Texture.cpp:11-16: multiply, then rotate right by the value itself (mod 32) */
+static inline uint32_t lattice(uint32_t n)
+{
+    n = 1099087573u * n;
+    uint32_t s = n & 31u;
+    return s ? ((n >> s) | (n << (32u - s))) : n;
+}
+
+struct F4 { float x, y, z, w; };
+static inline double dot4(const F4 &a, const F4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }   /* Texture.cpp:24-28 */
+
+struct NoiseState {     /* the reference's file-static scratch (Texture.cpp:30-32), made local */
+    F4       grad[9], coef[9];
+    uint32_t flr[9];
+};
+
+static const float kHalf32 = 0.5f * 4294967296.0f;
+
+/* Texture.cpp:34-59 */
+static float spline(NoiseState &s, int dim, uint32_t lat)
+{
+    uint32_t f = s.flr[dim];
+    uint32_t h0 = lattice((f - 1) ^ lat), h1 = lattice(f ^ lat), h2 = lattice((f + 1) ^ lat), h3 = lattice((f + 2) ^ lat);
+    F4 k;
+    if (dim == 1) {
+        k.x = float(h0) - kHalf32; k.y = float(h1) - kHalf32; k.z = float(h2) - kHalf32; k.w = float(h3) - kHalf32;
+    } else {
+        k.x = spline(s, dim - 1, h0); k.y = spline(s, dim - 1, h1); k.z = spline(s, dim - 1, h2); k.w = spline(s, dim - 1, h3);
+    }
+    return float(dot4(s.coef[dim], k));
+}
+
+static void setup(NoiseState &s, const float *p, int ndim, float &gain, bool with_grad)
+{
+    gain = 1.0f;
+    for (int i = 0; i < ndim; i++) {
+        gain *= 1.27f;
+        int d = ndim - i;
+        int fl = int(p[i]) - (p[i] < 0.0f && p[i] != int(p[i]));
+        float x = p[i] - fl;
+        s.flr[d] = (uint32_t)fl;
+        s.coef[d].x = 1.0f / 6.0f + x * (x * (0.5f - 1.0f / 6.0f * x) - 0.5f);
+        s.coef[d].y = 4.0f / 6.0f + x * x * (0.5f * x - 1.0f);
+        s.coef[d].z = 1.0f / 6.0f + 0.5f * x * (1.0f + x * (1.0f - x));
+        s.coef[d].w = 1.0f / 6.0f * x * x * x;
+        if (with_grad) {
+            s.grad[d].x = -0.5f + x * (1.0f - 0.5f * x);
+            s.grad[d].y = x * (1.5f * x - 2.0f);
+            s.grad[d].z = 0.5f + x * (1.0f - 1.5f * x);
+            s.grad[d].w = 0.5f * x * x;
+        }
+    }
+}
+
+/* Texture.cpp:98-123 (nPow == 1) */
+float band_noise(const float *p, int ndim)
+{
+    NoiseState s;
+    float gain;
+    setup(s, p, ndim, gain, false);
+    return gain * spline(s, ndim, 1099087573u) * (0.9f / 4294967296.0f) + 0.5f;
+}
+
+/* Texture.cpp:127-157 */
+static float grad_spline(NoiseState &s, float *g, int dim, uint32_t lat, int stride)
+{
+    uint32_t f = s.flr[dim];
+    uint32_t h0 = lattice((f - 1) ^ lat), h1 = lattice(f ^ lat), h2 = lattice((f + 1) ^ lat), h3 = lattice((f + 2) ^ lat);
+    F4 k, gk[8];
+    if (dim == 1) {
+        k.x = float(h0) - kHalf32; k.y = float(h1) - kHalf32; k.z = float(h2) - kHalf32; k.w = float(h3) - kHalf32;
+    } else {
+        k.x = grad_spline(s, &gk[0].x, dim - 1, h0, 4);
+        k.y = grad_spline(s, &gk[0].y, dim - 1, h1, 4);
+        k.z = grad_spline(s, &gk[0].z, dim - 1, h2, 4);
+        k.w = grad_spline(s, &gk[0].w, dim - 1, h3, 4);
+    }
+    int is = stride;
+    for (int i = 1; i < dim; i++, is += stride)
+        g[is] = float(dot4(s.coef[dim], gk[i - 1]));
+    g[0] = float(dot4(s.grad[dim], k));
+    return float(dot4(s.coef[dim], k));
+}
+
+/* Texture.cpp:159-191 (nPow == 1) */
+float gradient_band_noise(float *g, const float *p, int ndim)
+{
+    NoiseState s;
+    float gain;
+    setup(s, p, ndim, gain, true);
+    float v = gain * grad_spline(s, g, ndim, 123456789u, 1) * (0.9f / 4294967296.0f) + 0.5f;
+    for (int i = 0; i < ndim; i++)
+        g[i] *= gain * (0.9f / 4294967296.0f);
+    return v;
+}
+
+/* TextureMaps.cpp:189-198 */
+static void perturb(Hit &h, const V3 &d)
+{
+    if (h.perturbed) {
+        h.np = h.np + d;
+    } else {
+        h.np = normalize(h.n) + d;
+        h.perturbed++;
+    }
+}
+
+static void bump3(const V3 &p, Hit &h, double scale)      /* Bumpy / MicroFacets / MicroFacets2: TextureMaps.cpp:209-249 */
+{
+    float q[3] = { float(p.x * scale), float(p.y * scale), float(p.z * scale) }, g[3];
+    gradient_band_noise(g, q, 3);
+    perturb(h, V3(g[0], g[1], g[2]) * 0.3);
+}
+
+extern const V3 kDodecahedronNormals[20];
+
+void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
+{
+    switch (tex) {
+    case RT_TEX_BUMPY:        bump3(p, h, 50.0); return;
+    case RT_TEX_MICROFACETS:  bump3(p, h, 500.0); return;
+    case RT_TEX_MICROFACETS2: bump3(p, h, 5000.0); return;
+    case RT_TEX_FIBERS: {                                   /* TextureMaps.cpp:338-349 */
+        float q[3] = { float(p.x * 250.0), float(p.y * 250.0), 0.0f }, g[3];
+        gradient_band_noise(g, q, 2);
+        perturb(h, V3(g[0], g[1], 0.0) * 0.3);
+        return;
+    }
+    case RT_TEX_BLISTERED: {                                /* TextureMaps.cpp:351-369 */
+        float q[3] = { float(p.x * 25.0), float(p.y * 25.0), float(p.z * 25.0) }, g[3], f;
+        f = gradient_band_noise(g, q, 3);
+        if (f > 0.5) f = -0.5; else f = 0.0;
+        perturb(h, V3(g[0], g[1], g[2]) * f);
+        return;
+    }
+    case RT_TEX_FACETED20: {                                /* TextureMaps.cpp:281-305 */
+        float q[3] = { float(p.x * 50.0), float(p.y * 50.0), float(p.z * 50.0) }, g[3];
+        gradient_band_noise(g, q, 3);
+        V3 cv(g[0], g[1], g[2]), best;
+        double bestd = -1000000.0;
+        for (int i = 0; i < 20; i++) {
+            double d = dot(cv, kDodecahedronNormals[i]);
+            if (d > bestd) { bestd = d; best = kDodecahedronNormals[i]; }
+        }
+        perturb(h, best * 0.15);
+        return;
+    }
+    case RT_TEX_WAVY: {                                     /* TextureMaps.cpp:330-336: CoVector3(double) splats the scalar */
+        double f = 0.3 * cos(p.z / (2.0 * kPi));
+        perturb(h, V3(f, f, f));
+        return;
+    }
+    case RT_TEX_QUASIMICROFACET: {                          /* TextureMaps.cpp:251-265 */
+        V3 n = h.perturbed ? h.np : h.n;
+        V3 cu = normalize(cross(n, V3(0.0, 1.0, 0.0)));
+        V3 cvv = normalize(cross(n, cu));
+        double u = cx.aux[4], v = cx.aux[5];
+        u = u * u * u * u * u;
+        v = v * v * v * v * v;
+        perturb(h, (cu * u + cvv * v) * 0.25);
+        return;
+    }
+    default:
+        return;
+    }
+}
+
+/* rgvDodecahedron, Solids.cpp:649-711 */
+#define T_  (1.0 / kSqrt3)
+#define P1_ (1.61803398874989484820458683436563811772030917980576 / kSqrt3)
+#define P2_ ((1.61803398874989484820458683436563811772030917980576 - 1.0) / kSqrt3)
+const V3 kDodecahedronNormals[20] = {
+    V3(T_, T_, T_), V3(T_, T_, -T_), V3(T_, -T_, T_), V3(T_, -T_, -T_),
+    V3(-T_, T_, T_), V3(-T_, T_, -T_), V3(-T_, -T_, T_), V3(-T_, -T_, -T_),
+    V3(0.0, P2_, P1_), V3(0.0, P2_, -P1_), V3(0.0, -P2_, P1_), V3(0.0, -P2_, -P1_),
+    V3(P1_, 0.0, P2_), V3(P1_, 0.0, -P2_), V3(-P1_, 0.0, P2_), V3(-P1_, 0.0, -P2_),
+    V3(P2_, P1_, 0.0), V3(P2_, -P1_, 0.0), V3(-P2_, P1_, 0.0), V3(-P2_, -P1_, 0.0)
+};
+
+} // namespace orc

@@ -1,0 +1,229 @@
+"""ctypes bindings: struct mirrors of include/rt_scene_desc.h and the entry points of
+librt_amd.so (include/rt_amd.h) and librt_frontend.so (frontend/rt_scenes.cpp)."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_RT = os.path.join(HERE, "librt_amd.so")
+LIB_FRONTEND = os.path.join(HERE, "librt_frontend.so")
+TABLES = os.path.join(HERE, "data", "tables.bin")
+NSPEC = 10
+BLUE_N = 1600
+
+
+class RtNode(C.Structure):
+    _fields_ = [("type", C.c_int32), ("id", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
+                ("i0", C.c_int32), ("i1", C.c_int32), ("i2", C.c_int32), ("link", C.c_int32),
+                ("data", C.c_int32), ("ndata", C.c_int32)]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("type", C.c_int32), ("no_shadow", C.c_int32), ("org", C.c_double * 3),
+                ("vA", C.c_double * 3), ("vB", C.c_double * 3), ("flux", C.c_float * NSPEC)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pad_", C.c_int32), ("org", C.c_double * 3), ("focal", C.c_double),
+                ("vX", C.c_double * 3), ("vY", C.c_double * 3), ("focus_distance", C.c_double)]
+
+
+class RtSampler(C.Structure):
+    _fields_ = [("type", C.c_int32), ("venera", C.c_int32), ("qindex2", C.POINTER(C.c_int32)),
+                ("qindex3", C.POINTER(C.c_int32)), ("aux_init", C.c_double * 6)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("root", C.c_int32), ("nodes", C.POINTER(RtNode)),
+                ("n_data", C.c_int32), ("n_lights", C.c_int32), ("data", C.POINTER(C.c_double)),
+                ("lights", C.POINTER(RtLight)), ("has_ambient", C.c_int32), ("ambient_flux", C.c_float * NSPEC),
+                ("camera", RtCamera), ("sampler", RtSampler)]
+
+
+class RtRenderDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_double), ("row0", C.c_int32), ("row1", C.c_int32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("samples", C.c_int64), ("rays_primary", C.c_int64), ("rays_shadow", C.c_int64),
+                ("rays_secondary", C.c_int64), ("hit_overflow", C.c_int64), ("seconds", C.c_double),
+                ("seconds_trace", C.c_double), ("seconds_reconstruct", C.c_double)]
+
+    def rays(self):
+        return self.rays_primary + self.rays_shadow + self.rays_secondary
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+_frontend = None
+_rt = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def rt_lib():
+    """librt_amd.so -- the HIP library.  Fails loudly when it has not been built."""
+    global _rt
+    if _rt is None:
+        if not os.path.exists(LIB_RT):
+            raise RtError("librt_amd.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        L = C.CDLL(LIB_RT, mode=C.RTLD_GLOBAL)
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_scene_upload.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_void_p)]
+        L.rt_scene_free.argtypes = [C.c_void_p]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.POINTER(C.c_float), C.POINTER(RtStats)]
+        L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.c_void_p, C.POINTER(RtStats), C.c_void_p]
+        L.rt_probe_samples.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.rt_probe_camera.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rt_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rt_probe_radiance.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)]
+        L.rt_probe_sample_rgb.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.POINTER(C.c_float), C.c_int64, C.POINTER(RtStats)]
+        L.rt_build_quasi_index.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.rt_random_unsigned.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
+        L.rt_set_option.argtypes = [C.c_char_p, C.c_int64]
+        _rt = L
+    return _rt
+
+
+def frontend_lib():
+    global _frontend
+    if _frontend is None:
+        rt_lib()  # the front end links against the C ABI
+        if not os.path.exists(LIB_FRONTEND):
+            raise RtError("librt_frontend.so is missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_FRONTEND, mode=C.RTLD_GLOBAL)
+        L.rtf_last_error.restype = C.c_char_p
+        L.rtf_scene_build.restype = C.c_void_p
+        L.rtf_scene_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.rtf_scene_desc.restype = C.POINTER(RtSceneDesc)
+        L.rtf_scene_desc.argtypes = [C.c_void_p]
+        L.rtf_scene_free.argtypes = [C.c_void_p]
+        L.rtf_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(RtStats)]
+        L.rtf_extent.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        L.rtf_random_double.argtypes = [C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_double)]
+        _frontend = L
+    return _frontend
+
+
+class FrontScene:
+    """A scene built by the host front end (named scene S0/S1/S2 or scene text), flattened."""
+
+    def __init__(self, spec, sampler="", optimize=True):
+        L = frontend_lib()
+        self._L = L
+        self.h = L.rtf_scene_build(spec.encode(), sampler.encode(), 1 if optimize else 0)
+        if not self.h:
+            raise RtError(L.rtf_last_error().decode())
+        self.desc = L.rtf_scene_desc(self.h)
+
+    def node_ids(self):
+        d = self.desc.contents
+        return [d.nodes[i].id for i in range(d.n_nodes)]
+
+    def render(self, width, height, spp):
+        planes = np.zeros((3, height, width), dtype=np.float32)
+        st = RtStats()
+        n = self._L.rtf_scene_render(self.h, width, height, float(spp), _p(planes, C.c_float), C.byref(st))
+        if n < 0:
+            raise RtError(self._L.rtf_last_error().decode())
+        return planes, st
+
+    def close(self):
+        if self.h:
+            self._L.rtf_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuScene:
+    """rt_scene handle on the current HIP device (C ABI)."""
+
+    def __init__(self, desc):
+        self.L = rt_lib()
+        h = C.c_void_p()
+        rc = self.L.rt_scene_upload(desc, C.byref(h))
+        if rc:
+            raise RtError("rt_scene_upload: %d %s" % (rc, self.L.rt_last_error().decode()))
+        self.h = h
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RtError("%s: %d %s" % (what, rc, self.L.rt_last_error().decode()))
+
+    def render(self, width, height, spp, row0=0, row1=0):
+        planes = np.zeros((3, height, width), dtype=np.float32)
+        rd = RtRenderDesc(width, height, float(spp), row0, row1)
+        st = RtStats()
+        self._chk(self.L.rt_render(self.h, C.byref(rd), _p(planes, C.c_float), C.byref(st)), "rt_render")
+        return planes, st
+
+    def render_device(self, width, height, spp, dev_ptr, stream=0, row0=0, row1=0):
+        rd = RtRenderDesc(width, height, float(spp), row0, row1)
+        st = RtStats()
+        self._chk(self.L.rt_render_device(self.h, C.byref(rd), C.c_void_p(dev_ptr), C.byref(st), C.c_void_p(stream)), "rt_render_device")
+        return st
+
+    def samples(self, width, height, spp, first, n):
+        rd = RtRenderDesc(width, height, float(spp), 0, 0)
+        out8 = np.zeros((n, 8)); xy = np.zeros((n, 2)); tot = C.c_int64()
+        self._chk(self.L.rt_probe_samples(self.h, C.byref(rd), first, n, _p(out8, C.c_double), _p(xy, C.c_double), C.byref(tot)), "rt_probe_samples")
+        return out8, xy, tot.value
+
+    def camera(self, v2, aux=None):
+        v2 = np.ascontiguousarray(v2, dtype=np.float64); n = len(v2)
+        org = np.zeros((n, 3)); dr = np.zeros((n, 3))
+        a = None if aux is None else _p(np.ascontiguousarray(aux, dtype=np.float64), C.c_double)
+        self._chk(self.L.rt_probe_camera(self.h, n, _p(v2, C.c_double), a, _p(org, C.c_double), _p(dr, C.c_double)), "rt_probe_camera")
+        return org, dr
+
+    def intersect(self, org, dr, aux=None, max_hits=8, transform=0):
+        org = np.ascontiguousarray(org, dtype=np.float64); dr = np.ascontiguousarray(dr, dtype=np.float64); n = len(org)
+        cnt = np.zeros(n, dtype=np.int32); t = np.zeros((n, max_hits)); nn = np.zeros((n, max_hits, 3))
+        leaf = np.zeros((n, max_hits), dtype=np.int32); mat = np.zeros_like(leaf); surf = np.zeros_like(leaf)
+        auxa = None if aux is None else np.ascontiguousarray(aux, dtype=np.float64)
+        a = None if auxa is None else _p(auxa, C.c_double)
+        self._chk(self.L.rt_probe_intersect(self.h, n, _p(org, C.c_double), _p(dr, C.c_double), a, max_hits, transform,
+                                            _p(cnt, C.c_int), _p(t, C.c_double), _p(nn, C.c_double), _p(leaf, C.c_int), _p(mat, C.c_int), _p(surf, C.c_int)), "rt_probe_intersect")
+        return cnt, t, nn, leaf, mat, surf
+
+    def radiance(self, org, dr, aux=None):
+        org = np.ascontiguousarray(org, dtype=np.float64); dr = np.ascontiguousarray(dr, dtype=np.float64); n = len(org)
+        out = np.zeros((n, NSPEC), dtype=np.float32)
+        auxa = None if aux is None else np.ascontiguousarray(aux, dtype=np.float64)
+        a = None if auxa is None else _p(auxa, C.c_double)
+        self._chk(self.L.rt_probe_radiance(self.h, n, _p(org, C.c_double), _p(dr, C.c_double), a, _p(out, C.c_float)), "rt_probe_radiance")
+        return out
+
+    def sample_rgb(self, width, height, spp, max_samples):
+        rd = RtRenderDesc(width, height, float(spp), 0, 0)
+        out = np.zeros((max_samples, 3), dtype=np.float32); st = RtStats()
+        self._chk(self.L.rt_probe_sample_rgb(self.h, C.byref(rd), _p(out, C.c_float), max_samples, C.byref(st)), "rt_probe_sample_rgb")
+        return out[:st.samples], st
+
+    def close(self):
+        if self.h:
+            self.L.rt_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_quasi_index(prime, n):
+    out = np.zeros(n, dtype=np.int32)
+    rt_lib().rt_build_quasi_index(_p(out, C.c_int), prime, n)
+    return out

@@ -1,0 +1,710 @@
+/*
+ * rt_frontend.cpp -- implementation of the host scene API (rt_frontend.h): scene construction
+ * helpers, Optimize(), GetExtent(), flattening to RtSceneDesc, and RayTracer::Render, which calls
+ * the HIP library through the C ABI (include/rt_amd.h).  No ray is ever intersected here.
+ */
+#include <stdlib.h>
+#include <dlfcn.h>
+#include <map>
+#include <string>
+#include "rt_frontend.h"
+#include "../../include/rt_amd.h"
+#include "../csrc/rt_tables.h"
+
+/* ------------------------------------------------------------------------------ constants ---- */
+static Spectrum table_spectrum(const char *name)
+{
+    Spectrum s;
+    int dt = 0, cnt = 0;
+    const void *p = rt_table_find(name, &dt, &cnt);
+    if (!p || dt != RT_TABLE_F32 || cnt != NSPEC) { fprintf(stderr, "rt_frontend: missing table %s\n", name); abort(); }
+    memcpy(s.rgf, p, sizeof s.rgf);
+    return s;
+}
+static DisplayRGB table_rgb(const char *name)
+{
+    int dt = 0, cnt = 0;
+    const float *p = (const float *)rt_table_find(name, &dt, &cnt);
+    if (!p || dt != RT_TABLE_F32 || cnt != 3) { fprintf(stderr, "rt_frontend: missing table %s\n", name); abort(); }
+    DisplayRGB c; c.red = p[0]; c.grn = p[1]; c.blu = p[2];
+    return c;
+}
+#define SPEC(n) Spectrum n = table_spectrum(#n)
+SPEC(g_sRed); SPEC(g_sGreen); SPEC(g_sBlue); SPEC(g_sYellow); SPEC(g_sCyan); SPEC(g_sMagenta); SPEC(g_sWhite); SPEC(g_sOrange);
+SPEC(g_sBlack); SPEC(g_sEqualWhite); SPEC(g_sD6500);
+SPEC(g_sWater); SPEC(g_sCobaltGlass); SPEC(g_sCopper); SPEC(g_sGold); SPEC(g_sRuby); SPEC(g_sEmerald); SPEC(g_sSapphire); SPEC(g_sWhiskey);
+SPEC(g_sEarthSky); SPEC(g_sSolar); SPEC(g_sIllumD65);
+#define RGBC(n) DisplayRGB n = table_rgb(#n)
+RGBC(g_rgbIron); RGBC(g_rgbCopper); RGBC(g_rgbGold); RGBC(g_rgbZinc); RGBC(g_rgbZilver); RGBC(g_rgbAluminum); RGBC(g_rgbSilicon);
+DisplayRGB SpectrumToRGB[NSPEC];
+Vector2 g_rgvBlueNoise[BLUE_N];
+int g_BlueNoiseQuasiIndex2[BLUE_N], g_BlueNoiseQuasiIndex3[BLUE_N];
+double g_uCamera, g_vCamera, g_uLight, g_vLight, g_uMicroFacet, g_vMicroFacet;
+
+namespace {
+struct TableInit {
+    TableInit()
+    {
+        int dt, cnt;
+        const float *m = (const float *)rt_table_find("SpectrumToRGB", &dt, &cnt);
+        for (int i = 0; i < NSPEC; i++) { SpectrumToRGB[i].red = m[3 * i]; SpectrumToRGB[i].grn = m[3 * i + 1]; SpectrumToRGB[i].blu = m[3 * i + 2]; }
+        const double *b = (const double *)rt_table_find("g_rgvBlueNoise", &dt, &cnt);
+        for (int i = 0; i < BLUE_N; i++) g_rgvBlueNoise[i] = Vector2(b[2 * i], b[2 * i + 1]);
+        /* the reference ships these two permutations precomputed (BlueNoiseTile.cpp:1607, :1810) */
+        BuildQuasiIndex(g_BlueNoiseQuasiIndex2, 2, BLUE_N);
+        BuildQuasiIndex(g_BlueNoiseQuasiIndex3, 3, BLUE_N);
+    }
+} s_table_init;
+}
+
+const Spectrum *rt_spectrum_by_name(const char *name)
+{
+    static std::map<std::string, Spectrum> cache;
+    std::map<std::string, Spectrum>::iterator it = cache.find(name);
+    if (it != cache.end()) return &it->second;
+    int dt, cnt;
+    if (!rt_table_find(name, &dt, &cnt) || dt != RT_TABLE_F32 || cnt != NSPEC) return 0;
+    cache[name] = table_spectrum(name);
+    return &cache[name];
+}
+
+DisplayRGB Spectrum::sRGB() const
+{
+    DisplayRGB c(0.0, 0.0, 0.0);
+    for (int i = 0; i < NSPEC; i++) {
+        double w = rgf[i] * (5.0 / 10.0);
+        c.red = c.red + float(SpectrumToRGB[i].red * w);
+        c.grn = c.grn + float(SpectrumToRGB[i].grn * w);
+        c.blu = c.blu + float(SpectrumToRGB[i].blu * w);
+    }
+    return c;
+}
+
+/* RadiometryColor.cpp:947-969 */
+Spectrum RGBtoSpectrum(DisplayRGB c, int n6500)
+{
+    Spectrum s;
+    if (c.red < c.grn && c.red < c.blu)
+        s = g_sWhite * c.red + g_sGreen * (c.grn - c.red) + g_sBlue * (c.blu - c.red);
+    else if (c.grn < c.red && c.grn < c.blu)
+        s = g_sWhite * c.grn + g_sRed * (c.red - c.grn) + g_sBlue * (c.blu - c.grn);
+    else
+        s = g_sWhite * c.blu + g_sRed * (c.red - c.blu) + g_sGreen * (c.grn - c.blu);
+    if (n6500) s = s / g_sD6500;
+    return s;
+}
+Spectrum RGBtoSpectrum(double f) { return g_sWhite * f; }
+
+/* RadiometryColor.cpp:985-1012 */
+Spectrum BlackBody(double kelvin)
+{
+    if (kelvin < 0.0) return g_sBlack;
+    const double h = 6.62606876e-34, c = 2.99792458e+8, kB = 1.3806503e-23;
+    double c1 = 2.0 * D_PI * h * c * c, c2 = h * c / kB;
+    Spectrum sd;
+    for (int i = 0; i < NSPEC; i++) {
+        double lambda = 1.0e-9 * (380 + 40 * double(i));
+        double x = c2 / lambda / kelvin, em1;
+        if (x < -0.0001 || x > 0.0001) em1 = exp(x) - 1.0;
+        else em1 = x * (1.0 + 0.5 * x * (1.0 + x / 3.0 * (1.0 + 0.25 * x)));
+        double planck = c1 / (lambda * lambda * lambda * lambda * lambda * em1);
+        sd.rgf[i] = float(planck / 30932027310080.0) / 12.0f;
+    }
+    return sd * 1.98;
+}
+
+/* ---------------------------------------------------------------------------------- PRNG ---- */
+unsigned ML_nMarsagliaX = 886459, ML_nMarsagliaC = 361290869;
+unsigned RandomUnsigned()
+{
+    uint64_t n = (uint64_t)1965537969u * ML_nMarsagliaX + ML_nMarsagliaC;
+    ML_nMarsagliaX = (unsigned)(n & 0xFFFFFFFFu);
+    ML_nMarsagliaC = (unsigned)(n >> 32);
+    return ML_nMarsagliaX;
+}
+double RandomDouble()
+{
+    double hi = double(RandomUnsigned());       /* first draw is the high word (left operand first) */
+    double lo = double(RandomUnsigned());
+    return (hi + lo * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0);
+}
+float RandomFloat() { return float(RandomUnsigned()) * (1.0f / 4294967296.0f); }
+unsigned RandomLessThanN(unsigned mod)
+{
+    unsigned rem = 0xFFFFFFFFu % mod, n;
+    do { n = RandomUnsigned(); } while (n <= rem);
+    return n % mod;
+}
+void ML_InitializeRandom(unsigned x, unsigned c) { ML_nMarsagliaX = x; ML_nMarsagliaC = c; }
+
+/* Radical-inverse permutation of 0..n-1 in base `prime` (Patterns.cpp:1697-1736): element k of the
+   result is the k-th index when indices are ordered by their digit-reversed value; ties keep index
+   order.  Computed directly from the reversed digit string instead of the reference's recursive
+   bucket sort. */
+void BuildQuasiIndex(int rgn[], int prime, int n)
+{
+    rt_build_quasi_index(rgn, prime, n);
+}
+
+void FibonacciSphere(double rgf[], int i, int n)       /* Patterns.cpp:1850-1865 */
+{
+    double u = fmod(double(i) / D_PHI, 1.0), v = double(i) / double(n);
+    double z = 2.0 * v - 1.0, r = sqrt(1.0 - z * z);
+    rgf[0] = r * sin(2.0 * D_PI * u);
+    rgf[1] = r * cos(2.0 * D_PI * u);
+    rgf[2] = z;
+}
+
+/* ------------------------------------------------------------------------------ matrices ---- */
+static void basis_rotate(int i1, int i2, double rad, Matrix3 &mat, bool initial)   /* Affine.cpp:36-65 */
+{
+    double s = sin(rad), c = cos(rad);
+    if (initial) {
+        mat.m[i1][i1] = c; mat.m[i1][i2] = -s; mat.m[i2][i1] = s; mat.m[i2][i2] = c;
+        return;
+    }
+    for (int j = 0; j < 3; j++) {
+        double x = c * mat.m[i1][j] - s * mat.m[i2][j];
+        mat.m[i2][j] = s * mat.m[i1][j] + c * mat.m[i2][j];
+        mat.m[i1][j] = x;
+    }
+}
+Matrix3 EulerMatrix(double r0, double r1, double r2, const char *cv)              /* Affine.cpp:67-97 */
+{
+    Matrix3 mat(1.0);
+    const double r[3] = { r0, r1, r2 };
+    for (int k = 0; k < 3; k++) {
+        int a, b;
+        switch (cv[k]) {
+        case 'x': a = 1; b = 2; break;
+        case 'y': a = 2; b = 0; break;
+        case 'z': a = 0; b = 1; break;
+        default: continue;
+        }
+        basis_rotate(a, b, r[k], mat, k == 0);
+    }
+    return mat;
+}
+static Matrix3 axis_angle(const Vector3 &n, double s, double c)
+{
+    Matrix3 mat;
+    double t = 1.0 - c;
+    mat.m[0][0] = t * n.x * n.x + c;
+    mat.m[1][1] = t * n.y * n.y + c;
+    mat.m[2][2] = t * n.z * n.z + c;
+    mat.m[0][1] = t * n.x * n.y + s * n.z;
+    mat.m[1][0] = t * n.x * n.y - s * n.z;
+    mat.m[0][2] = t * n.x * n.z - s * n.y;
+    mat.m[2][0] = t * n.x * n.z + s * n.y;
+    mat.m[1][2] = t * n.y * n.z + s * n.x;
+    mat.m[2][1] = t * n.y * n.z - s * n.x;
+    return mat;
+}
+Matrix3 RotateAboutAxis(const Vector3 &axis, double rad)                          /* Affine.cpp:99-120 */
+{
+    return axis_angle(Normalize(axis), sin(-rad), cos(-rad));
+}
+Matrix3 RotateFromTo(const Vector3 &from, const Vector3 &to)                      /* Affine.cpp:122-153 */
+{
+    Vector3 a = Normalize(from), b = Normalize(to), n = Cross(a, b);
+    double s = Norm(n), c = Dot(a, b);
+    if (s < 1.0e-8) {
+        if (c > 0.0) return Matrix3(1.0);
+        return RotateAboutAxis(Vector3(1.0, 0.0, 0.0), D_PI);
+    }
+    n = n / s;
+    return axis_angle(n, -s, c);
+}
+Matrix3 InverseMatrix(const Matrix3 &a)                                           /* Affine.cpp:6-31 */
+{
+    double f1 = a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1];
+    double f2 = a.m[1][2] * a.m[2][0] - a.m[1][0] * a.m[2][2];
+    double f3 = a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0];
+    double det = a.m[0][0] * f1 + a.m[0][1] * f2 + a.m[0][2] * f3;
+    double di = det ? (1.0 / det) : 0.0;
+    return Matrix3(f1 * di, -(a.m[0][1] * a.m[2][2] - a.m[0][2] * a.m[2][1]) * di, (a.m[0][1] * a.m[1][2] - a.m[0][2] * a.m[1][1]) * di,
+                   f2 * di, (a.m[0][0] * a.m[2][2] - a.m[0][2] * a.m[2][0]) * di, -(a.m[0][0] * a.m[1][2] - a.m[0][2] * a.m[1][0]) * di,
+                   f3 * di, -(a.m[0][0] * a.m[2][1] - a.m[0][1] * a.m[2][0]) * di, (a.m[0][0] * a.m[1][1] - a.m[0][1] * a.m[1][0]) * di);
+}
+
+/* -------------------------------------------------------------------------------- solids ---- */
+static int s_serial = 0;
+Solid::Solid() : nIsAffine(0), nSerial(s_serial++) {}
+
+#define T_  1.0 / D_SQRT3
+#define P1_ D_PHI / D_SQRT3
+#define P2_ (D_PHI - 1.0) / D_SQRT3
+#define I1_ 0.52573111211913
+#define I2_ 0.85065080835204
+CoVector3 rgvTetrahedron[4] = { CoVector3(T_, T_, T_), CoVector3(T_, -T_, -T_), CoVector3(-T_, T_, -T_), CoVector3(-T_, -T_, T_) };
+CoVector3 rgvCube[8] = { CoVector3(T_, T_, T_), CoVector3(T_, T_, -T_), CoVector3(T_, -T_, T_), CoVector3(T_, -T_, -T_),
+                         CoVector3(-T_, T_, T_), CoVector3(-T_, T_, -T_), CoVector3(-T_, -T_, T_), CoVector3(-T_, -T_, -T_) };
+CoVector3 rgvOctahedron[6] = { CoVector3(1.0, 0.0, 0.0), CoVector3(-1.0, 0.0, 0.0), CoVector3(0.0, 1.0, 0.0),
+                               CoVector3(0.0, -1.0, 0.0), CoVector3(0.0, 0.0, 1.0), CoVector3(0.0, 0.0, -1.0) };
+CoVector3 rgvDodecahedron[20] = {
+    CoVector3(T_, T_, T_), CoVector3(T_, T_, -T_), CoVector3(T_, -T_, T_), CoVector3(T_, -T_, -T_),
+    CoVector3(-T_, T_, T_), CoVector3(-T_, T_, -T_), CoVector3(-T_, -T_, T_), CoVector3(-T_, -T_, -T_),
+    CoVector3(0.0, P2_, P1_), CoVector3(0.0, P2_, -P1_), CoVector3(0.0, -P2_, P1_), CoVector3(0.0, -P2_, -P1_),
+    CoVector3(P1_, 0.0, P2_), CoVector3(P1_, 0.0, -P2_), CoVector3(-P1_, 0.0, P2_), CoVector3(-P1_, 0.0, -P2_),
+    CoVector3(P2_, P1_, 0.0), CoVector3(P2_, -P1_, 0.0), CoVector3(-P2_, P1_, 0.0), CoVector3(-P2_, -P1_, 0.0) };
+CoVector3 rgvIcosahedron[12] = {
+    CoVector3(I1_, 0.0, I2_), CoVector3(I1_, 0.0, -I2_), CoVector3(-I1_, 0.0, I2_), CoVector3(-I1_, 0.0, -I2_),
+    CoVector3(0.0, I2_, I1_), CoVector3(0.0, I2_, -I1_), CoVector3(0.0, -I2_, I1_), CoVector3(0.0, -I2_, -I1_),
+    CoVector3(I2_, I1_, 0.0), CoVector3(-I2_, I1_, 0.0), CoVector3(I2_, -I1_, 0.0), CoVector3(-I2_, -I1_, 0.0) };
+
+Prism::Prism(int n)                                     /* Solids.cpp:871-881 */
+{
+    nSides = n + 2;
+    rgv = new CoVector3[n + 2];
+    int i;
+    for (i = 0; i < n; i++) rgv[i] = CoVector3(sin(2.0 * i * D_PI / n), cos(2.0 * i * D_PI / n), 0.0);
+    rgv[i++] = CoVector3(0.0, 0.0, 1.0);
+    rgv[i++] = CoVector3(0.0, 0.0, -1.0);
+}
+Fibonacci::Fibonacci(int n)                             /* Solids.cpp:883-892 */
+{
+    nSides = n;
+    rgv = new CoVector3[n];
+    for (int i = 0; i < n; i++) { double f[3]; FibonacciSphere(f, i, n); rgv[i] = CoVector3(f[0], f[1], f[2]); }
+}
+
+Extent ConeHyperCylinder::GetExtent()                   /* Solids.cpp:360-371 */
+{
+    double r = Max(1.0, R), z;
+    if (R <= 1.0) z = 1.0; else z = sqrt(R * R / (R * R - 1.0));
+    return Extent(Point3(-r, -r, -z), Point3(r, r, +z));
+}
+
+Extent AffineSolid::GetExtent()                         /* Solids.cpp:922-947 */
+{
+    if (psChild == 0) return Extent(0.0);
+    Extent e = psChild->GetExtent();
+    Point3 c[2] = { e.pMin, e.pMax };
+    for (int i = 0; i < 8; i++) {
+        Point3 p(c[(i >> 0) & 1].x, c[(i >> 1) & 1].y, c[(i >> 2) & 1].z);
+        Point3 q = mTransform * p + vTranslate;
+        if (i == 0) e.pMin = e.pMax = q;
+        else { e.pMin = Min(e.pMin, q); e.pMax = Max(e.pMax, q); }
+    }
+    return e;
+}
+Extent Union::GetExtent()                               /* Solids.cpp:1077-1097 */
+{
+    if (psLeft && psRight) { Extent l = psLeft->GetExtent(), r = psRight->GetExtent(); return Extent(Min(l.pMin, r.pMin), Max(l.pMax, r.pMax)); }
+    if (psLeft) return psLeft->GetExtent();
+    if (psRight) return psRight->GetExtent();
+    return Extent(0.0);
+}
+Extent Intersection::GetExtent()                        /* Solids.cpp:1160-1175 */
+{
+    if (psLeft && psRight) { Extent l = psLeft->GetExtent(), r = psRight->GetExtent(); return Extent(Max(l.pMin, r.pMin), Min(l.pMax, r.pMax)); }
+    return Extent(0.0);
+}
+Extent Difference::GetExtent() { return psLeft ? psLeft->GetExtent() : Extent(0.0); }     /* Solids.cpp:1198-1204 */
+
+AngularClip::AngularClip(double f1, double f2, Solid *p) : ps(p)        /* Solids.cpp:1206-1222 */
+{
+    if (f2 - f1 <= D_PI) { nIntersect = 1; fAng1 = f1; fAng2 = f2; }
+    else { nIntersect = 0; fAng1 = f2; fAng2 = f1 + 2.0 * D_PI; }
+    cv1 = CoVector3(-cos(fAng1), +sin(fAng1), 0.0);
+    cv2 = CoVector3(+cos(fAng2), -sin(fAng2), 0.0);
+}
+
+/* Optimize(): merge affine chains and thread the parent links the shader walks to transform
+   normals (Solids.cpp:957-983, 1489-1528). */
+static AffineSolid *s_enclosing_affine = 0;
+Solid *AffineSolid::Optimize()
+{
+    if (psChild == 0) return 0;
+    while (psChild->nIsAffine) {
+        AffineSolid *c = (AffineSolid *)psChild;
+        Matrix3 m = mTransform * c->mTransform, mi = c->mInverse * mInverse;
+        Vector3 v = vTranslate + mTransform * c->vTranslate;
+        mTransform = m; mInverse = mi; vTranslate = v;
+        psChild = c->psChild;
+    }
+    paParent = s_enclosing_affine;
+    AffineSolid *saved = s_enclosing_affine;
+    s_enclosing_affine = this;
+    psChild = psChild->Optimize();
+    s_enclosing_affine = saved;
+    return this;
+}
+Solid *Material::Optimize() { paAffineTransforms = s_enclosing_affine; psChild = psChild->Optimize(); return this; }
+Solid *Surface::Optimize() { paAffineTransforms = s_enclosing_affine; psChild = psChild->Optimize(); return this; }
+
+static const int kLeftCount[13] = { 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5, 5, 6 };
+Solid *rt_make_union(Solid **ps, int n, int top)
+{
+    if (n <= 0) return 0;
+    if (n == 1) return ps[0];
+    if (n <= 5 && ps[0] == 0) return rt_make_union(ps + 1, n - 1, top);
+    int l = n <= 12 ? kLeftCount[n] : n / 2;
+    Solid *a = rt_make_union(ps, l, top), *b = rt_make_union(ps + l, n - l, top);
+    return top ? (Solid *)new TopUnion(a, b) : (Solid *)new Union(a, b);
+}
+Solid *rt_make_intersection(Solid **ps, int n)
+{
+    if (n <= 0) return 0;
+    if (n == 1) return ps[0];
+    int l = n <= 12 ? kLeftCount[n] : n / 2;
+    return new Intersection(rt_make_intersection(ps, l), rt_make_intersection(ps + l, n - l));
+}
+
+/* ---- shape library: Solids.cpp:1624-2009 ---- */
+static Solid *four_cylinders(double a, double b, double h, double r)
+{
+    Solid *c = new Translate(+a, +b, 0.0, new Scale(r, r, h, new Cylinder));
+    c = new Union(new Translate(+a, -b, 0.0, new Scale(r, r, h, new Cylinder)), c);
+    c = new Union(new Translate(-a, +b, 0.0, new Scale(r, r, h, new Cylinder)), c);
+    c = new Union(new Translate(-a, -b, 0.0, new Scale(r, r, h, new Cylinder)), c);
+    return c;
+}
+Solid *Cuboid(double r, double x, double y, double z)
+{
+    Solid *cubes = new Scale(x - r, y - r, z, new Cube);
+    cubes = new Union(new Scale(x - r, y, z - r, new Cube), cubes);
+    cubes = new Union(new Scale(x, y - r, z - r, new Cube), cubes);
+    Solid *ps = new Union(four_cylinders(x - r, y - r, z - r, r), cubes);
+    ps = new Union(new Rotate(0.5 * D_PI, 0.0, 0.0, four_cylinders(x - r, z - r, y - r, r)), ps);
+    ps = new Union(new Rotate(0.0, 0.5 * D_PI, 0.0, four_cylinders(z - r, y - r, x - r, r)), ps);
+    Solid *sph = 0;
+    for (int k = 0; k < 8; k++) {
+        double sx = (k & 4) ? -1.0 : 1.0, sy = (k & 2) ? -1.0 : 1.0, sz = (k & 1) ? -1.0 : 1.0;
+        Solid *one = new Translate(sx * (x - r), sy * (y - r), sz * (z - r), new Scale(r, r, r, new Sphere));
+        sph = sph ? (Solid *)new Union(one, sph) : one;
+    }
+    return new BoundingBox(new Union(sph, ps));
+}
+Solid *CylinderFromTo(const Point3 &from, const Point3 &to, double r)
+{
+    double L = Norm(to - from);
+    if (L == 0.0) printf("Zero length cylinder\n");
+    Solid *ps = new Scale(r, r, 0.5 * L, new Translate(0.0, 0.0, -1.0, new Cylinder));
+    ps = new Rotate(Vector3(0.0, 0.0, -1.0), to - from, ps);
+    return new Translate(from, ps);
+}
+static Point3 as_point(const CoVector3 &c) { return Point3(c.x, c.y, c.z); }
+static Solid *cage(const CoVector3 *v, int nv, double maxlen, double r, double rs, bool first_vertex_from_tetra)
+{
+    Solid *ps = 0;
+    if (r) {
+        for (int i = 0; i < nv; i++)
+            for (int j = i + 1; j < nv; j++) {
+                Point3 p1 = as_point(v[i]), p2 = as_point(v[j]);
+                if (maxlen > 0.0 && Norm(p1 - p2) > maxlen) continue;
+                Solid *c = CylinderFromTo(p1, p2, r);
+                ps = ps ? (Solid *)new Union(ps, c) : c;
+            }
+    }
+    if (rs) {
+        for (int i = 0; i < nv; i++) {
+            if (ps) ps = new Union(ps, new Translate(as_point(v[i]), new Scale(rs, rs, rs, new Sphere)));
+            else ps = new Translate(as_point(first_vertex_from_tetra ? rgvTetrahedron[i] : v[i]), new Scale(rs, rs, rs, new Sphere));
+        }
+    }
+    return new BoundingBox(ps);
+}
+Solid *TetrahedronCage(double r, double rs) { return cage(rgvTetrahedron, 4, 0.0, r, rs, false); }
+Solid *IcosahedronCage(double r, double rs) { return cage(rgvIcosahedron, 12, 1.1, r, rs, true); }     /* Solids.cpp:1766 uses Tetra(i) when r == 0 */
+Solid *DodecahedronCage(double r, double rs) { return cage(rgvDodecahedron, 20, 0.8, r, rs, false); }
+Solid *HexahedronCage(double r, double rs) { return cage(rgvCube, 8, 1.2, r, rs, false); }
+Solid *OctahedronCage(double r, double rs) { return cage(rgvOctahedron, 6, 1.9, r, rs, false); }
+Solid *Diskoid(double r) { return new BoundingBox(new Union(new Torus(r), new Scale(1.0, 1.0, r, new Cylinder))); }
+Solid *Rodoid(double r)
+{
+    return new BoundingBox(MakeUnion(new Scale(r, r, 1.0, new Cylinder),
+                                     new Translate(0.0, 0.0, +1.0, new Scale(r, r, r, new Sphere)),
+                                     new Translate(0.0, 0.0, -1.0, new Scale(r, r, r, new Sphere))));
+}
+Solid *Squareoid(double r)
+{
+    double f90 = 90.0 * D_PI / 180.0;
+    return new BoundingBox(MakeUnion(
+        new Scale(1.0, 1.0, r, new Cube),
+        new Translate(+1.0, +1.0, 0.0, new Scale(r, r, r, new Sphere)),
+        new Translate(+1.0, -1.0, 0.0, new Scale(r, r, r, new Sphere)),
+        new Translate(-1.0, +1.0, 0.0, new Scale(r, r, r, new Sphere)),
+        new Translate(-1.0, -1.0, 0.0, new Scale(r, r, r, new Sphere)),
+        new Translate(+1.0, 0.0, 0.0, new Rotate(f90, 0.0, 0.0, new Scale(r, r, 1.0, new Cylinder))),
+        new Translate(-1.0, 0.0, 0.0, new Rotate(f90, 0.0, 0.0, new Scale(r, r, 1.0, new Cylinder))),
+        new Translate(0.0, +1.0, 0.0, new Rotate(0.0, f90, 0.0, new Scale(r, r, 1.0, new Cylinder))),
+        new Translate(0.0, -1.0, 0.0, new Rotate(0.0, f90, 0.0, new Scale(r, r, 1.0, new Cylinder)))));
+}
+static void knob_geometry(double r, double z, double &rs, double &zDelta)
+{
+    double fTan = (1.0 - SSS(r)) / z;
+    double fCos = 1.0 / sqrt(1.0 + fTan * fTan);
+    rs = 1.0 / fCos;
+    zDelta = z + fTan;
+}
+Solid *Knoboid(double r, double z)
+{
+    double rs, zd;
+    knob_geometry(r, z, rs, zd);
+    return new BoundingBox(new Union(new Translate(0.0, 0.0, zd, new Scale(rs, rs, rs, new Sphere)),
+        new Scale(1.0, 1.0, z, new Intersection(new Scale(1.0, 1.0, 1.0, new Slab), new ConeHyperCylinder(r)))));
+}
+Solid *Knoboid2(double r, double z)
+{
+    double rs, zd;
+    knob_geometry(r, z, rs, zd);
+    return new BoundingBox(new Union(new Scale(rs, rs, rs, new Sphere),
+        new Translate(0.0, 0.0, -zd, new Scale(1.0, 1.0, z, new Intersection(new Scale(1.0, 1.0, 1.0, new Slab), new ConeHyperCylinder(r))))));
+}
+Solid *Hyperboloidoid(double r, double rt, double z)
+{
+    double fTan = (1.0 - r * r) / z;
+    double fCos = 1.0 / sqrt(1.0 + fTan * fTan);
+    double fSin = fTan * fCos;
+    fCos *= rt; fSin *= rt;
+    double zd = z + fSin, fS = 1.0 - fCos;
+    return new BoundingBox(new Union(new Translate(0.0, 0.0, zd, new Scale(fS, fS, fS, Diskoid(rt / fS))),
+        new Scale(1.0, 1.0, z, new Intersection(new Cube, new ConeHyperCylinder(r)))));
+}
+Solid *Slaboid(double x, double y, double z, double r)
+{
+    return new BoundingBox(MakeUnion(
+        new Scale(x - r, y, z, new Cube), new Scale(x, y - r, z, new Cube),
+        new Translate(+x - r, +y - r, 0.0, new Scale(r, r, z, new Cylinder)),
+        new Translate(+x - r, -y + r, 0.0, new Scale(r, r, z, new Cylinder)),
+        new Translate(-x + r, +y - r, 0.0, new Scale(r, r, z, new Cylinder)),
+        new Translate(-x + r, -y + r, 0.0, new Scale(r, r, z, new Cylinder))));
+}
+
+/* --------------------------------------------------------- texture / propagator identities ---- */
+#define TEXFN(name) void name(const Point3 &, Hit *, RayTracer *) {}
+TEXFN(Bumpy) TEXFN(MicroFacets) TEXFN(MicroFacets2) TEXFN(Wrinkled) TEXFN(Faceted20) TEXFN(Dented) TEXFN(Wavy)
+TEXFN(Fibers) TEXFN(Blistered) TEXFN(Hammered) TEXFN(Tectonic) TEXFN(QuasiMicroFacet)
+Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
+Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
+int rt_texture_id(TextureMap f)
+{
+    if (!f) return RT_TEX_NONE;
+    static const struct { TextureMap f; int id; } map[] = {
+        { Bumpy, RT_TEX_BUMPY }, { MicroFacets, RT_TEX_MICROFACETS }, { MicroFacets2, RT_TEX_MICROFACETS2 }, { Wrinkled, RT_TEX_WRINKLED },
+        { Faceted20, RT_TEX_FACETED20 }, { Dented, RT_TEX_DENTED }, { Wavy, RT_TEX_WAVY }, { Fibers, RT_TEX_FIBERS },
+        { Blistered, RT_TEX_BLISTERED }, { Hammered, RT_TEX_HAMMERED }, { Tectonic, RT_TEX_TECTONIC }, { QuasiMicroFacet, RT_TEX_QUASIMICROFACET } };
+    for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) if (map[i].f == f) return map[i].id;
+    return -1;
+}
+int rt_propagator_id(Propagator f)
+{
+    if (!f) return RT_PROP_NONE;
+    if (f == ColoredGlass) return RT_PROP_COLOREDGLASS;
+    if (f == Foggy) return RT_PROP_FOGGY;
+    return -1;
+}
+
+/* ---------------------------------------------------------------------------- flattening ---- */
+int RtSerializer::add(int type, const Solid *who)
+{
+    RtNode n;
+    memset(&n, 0, sizeof n);
+    n.type = type; n.id = who ? who->nSerial : -1; n.left = n.right = n.link = -1; n.data = (int)data.size();
+    nodes.push_back(n);
+    owner.push_back(who);
+    pending_link.push_back(0);
+    return (int)nodes.size() - 1;
+}
+int RtSerializer::push(const double *p, int n) { int o = (int)data.size(); data.insert(data.end(), p, p + n); return o; }
+void RtSerializer::resolve_links()
+{
+    std::map<const Solid *, int> where;
+    for (size_t i = 0; i < owner.size(); i++) where[owner[i]] = (int)i;
+    for (size_t i = 0; i < nodes.size(); i++) {
+        nodes[i].link = -1;
+        if (pending_link[i]) {
+            std::map<const Solid *, int>::iterator it = where.find(pending_link[i]);
+            if (it != where.end()) nodes[i].link = it->second;
+        }
+    }
+}
+static int emit_child(RtSerializer &s, Solid *c) { return c ? c->Emit(s) : -1; }
+
+int NullSolid::Emit(RtSerializer &s) { return s.add(RT_NODE_NULL, this); }
+int Quadric::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_QUADRIC, this);
+    double p[3] = { P, Q, R };
+    s.push(p, 3); s.nodes[i].ndata = 3; s.nodes[i].i0 = nClip;
+    return i;
+}
+int ConeHyperCylinder::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_CONEHYPERCYL, this);
+    double p[4] = { P, Q, Quadric::R, R };
+    s.push(p, 4); s.nodes[i].ndata = 4; s.nodes[i].i0 = nClip;
+    return i;
+}
+int ConvexPolyhedron::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_POLYHEDRON, this);
+    for (int k = 0; k < nSides; k++) { double p[3] = { rgv[k].x, rgv[k].y, rgv[k].z }; s.push(p, 3); }
+    s.nodes[i].ndata = 3 * nSides; s.nodes[i].i0 = nSides;
+    return i;
+}
+int Slab::Emit(RtSerializer &s) { return s.add(RT_NODE_SLAB, this); }
+int Torus::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_TORUS, this);
+    s.push(&fMinorRadius, 1); s.nodes[i].ndata = 1;
+    return i;
+}
+int AffineSolid::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_AFFINE, this);
+    double p[21];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { p[3 * r + c] = mTransform.m[r][c]; p[9 + 3 * r + c] = mInverse.m[r][c]; }
+    p[18] = vTranslate.x; p[19] = vTranslate.y; p[20] = vTranslate.z;
+    s.push(p, 21); s.nodes[i].ndata = 21;
+    s.pending_link[i] = paParent;
+    int c = emit_child(s, psChild);
+    s.nodes[i].left = c;
+    return i;
+}
+int BinarySolid::EmitBinary(RtSerializer &s, int type)
+{
+    int i = s.add(type, this);
+    int l = emit_child(s, psLeft);
+    int r = emit_child(s, psRight);
+    s.nodes[i].left = l; s.nodes[i].right = r;
+    return i;
+}
+int Union::Emit(RtSerializer &s) { return EmitBinary(s, RT_NODE_UNION); }
+int TopUnion::Emit(RtSerializer &s) { return EmitBinary(s, RT_NODE_TOPUNION); }
+int Intersection::Emit(RtSerializer &s) { return EmitBinary(s, RT_NODE_INTERSECTION); }
+int Difference::Emit(RtSerializer &s) { return EmitBinary(s, RT_NODE_DIFFERENCE); }
+int AngularClip::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_ANGULARCLIP, this);
+    double p[6] = { cv1.x, cv1.y, cv1.z, cv2.x, cv2.y, cv2.z };
+    s.push(p, 6); s.nodes[i].ndata = 6; s.nodes[i].i0 = nIntersect;
+    int c = emit_child(s, ps);
+    s.nodes[i].left = c;
+    return i;
+}
+int BoundingBox::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_BOUNDINGBOX, this);
+    double p[6] = { ex.pMin.x, ex.pMin.y, ex.pMin.z, ex.pMax.x, ex.pMax.y, ex.pMax.z };
+    s.push(p, 6); s.nodes[i].ndata = 6;
+    int c = emit_child(s, ps);
+    s.nodes[i].left = c;
+    return i;
+}
+int Material::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_MATERIAL, this);
+    double p[2 + NSPEC] = { fDensity, fRefractiveIndex };
+    for (int k = 0; k < NSPEC; k++) p[2 + k] = color.rgf[k];
+    s.push(p, 2 + NSPEC); s.nodes[i].ndata = 2 + NSPEC;
+    s.nodes[i].i0 = nLuster; s.nodes[i].i1 = rt_texture_id(Texture); s.nodes[i].i2 = rt_propagator_id(Propagate);
+    s.pending_link[i] = paAffineTransforms;
+    int c = emit_child(s, psChild);
+    s.nodes[i].left = c;
+    return i;
+}
+int Surface::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_SURFACE, this);
+    s.nodes[i].i0 = nRoughness; s.nodes[i].i1 = rt_texture_id(Texture);
+    s.pending_link[i] = paAffineTransforms;
+    int c = emit_child(s, psChild);
+    s.nodes[i].left = c;
+    return i;
+}
+
+void PerspectiveCamera::Describe(RtCamera &c) const { memset(&c, 0, sizeof c); c.type = RT_CAM_PERSPECTIVE; c.org[0] = pOrg.x; c.org[1] = pOrg.y; c.org[2] = pOrg.z; c.focal = focal; }
+void StereographicCamera::Describe(RtCamera &c) const { memset(&c, 0, sizeof c); c.type = RT_CAM_STEREOGRAPHIC; c.org[0] = pOrg.x; c.org[1] = pOrg.y; c.org[2] = pOrg.z; c.focal = focal; }
+void OrthographicCamera::Describe(RtCamera &c) const { memset(&c, 0, sizeof c); c.type = RT_CAM_ORTHOGRAPHIC; c.org[0] = pOrg.x; c.org[1] = pOrg.y; c.org[2] = pOrg.z; c.focal = focal; }
+void ApertureCamera::Describe(RtCamera &c) const
+{
+    StereographicCamera::Describe(c);
+    c.type = RT_CAM_APERTURE;
+    c.vX[0] = vX.x; c.vX[1] = vX.y; c.vX[2] = vX.z; c.vY[0] = vY.x; c.vY[1] = vY.y; c.vY[2] = vY.z;
+    c.focus_distance = fFocusDistance;
+}
+
+void FastBlueSamplingTile::QIndex1(int prime)                  /* Sampling.cpp:535-548 */
+{
+    if (prime > 0) {
+        BuildQuasiIndex(g_BlueNoiseQuasiIndex2, 2, BLUE_N);
+    } else {
+        for (int i = 0; i < BLUE_N; i++) g_BlueNoiseQuasiIndex2[i] = i;
+        if (prime < 0) RandomShuffle(g_BlueNoiseQuasiIndex2, BLUE_N);
+    }
+}
+
+static char s_err[512];
+const char *rt_frontend_last_error() { return s_err; }
+
+int rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen)
+{
+    RtSerializer &s = out.ser;
+    s.nodes.clear(); s.data.clear(); s.lights.clear(); s.owner.clear(); s.pending_link.clear();
+    int root = rt.psModel ? rt.psModel->Emit(s) : -1;
+    s.resolve_links();
+    for (size_t i = 0; i < s.nodes.size(); i++) {
+        if ((s.nodes[i].type == RT_NODE_MATERIAL || s.nodes[i].type == RT_NODE_SURFACE) && s.nodes[i].i1 < 0) { snprintf(err, errlen, "node %d: TextureMap is not one of the TextureMaps.h routines", (int)i); return -1; }
+        if (s.nodes[i].type == RT_NODE_MATERIAL && s.nodes[i].i2 < 0) { snprintf(err, errlen, "node %d: unknown Propagator", (int)i); return -1; }
+    }
+    for (PointLight *pl = rt.plPointLights; pl; pl = pl->plNext) {
+        RtLight l;
+        memset(&l, 0, sizeof l);
+        l.type = pl->IsArea() ? RT_LIGHT_AREA : RT_LIGHT_POINT;
+        l.no_shadow = pl->nNoShadow;
+        l.org[0] = pl->pOrg.x; l.org[1] = pl->pOrg.y; l.org[2] = pl->pOrg.z;
+        if (pl->IsArea()) {
+            const AreaLight *al = (const AreaLight *)pl;
+            l.vA[0] = al->vA.x; l.vA[1] = al->vA.y; l.vA[2] = al->vA.z; l.vB[0] = al->vB.x; l.vB[1] = al->vB.y; l.vB[2] = al->vB.z;
+        }
+        memcpy(l.flux, pl->flux.rgf, sizeof l.flux);
+        s.lights.push_back(l);
+    }
+    RtSceneDesc &d = out.desc;
+    memset(&d, 0, sizeof d);
+    d.n_nodes = (int)s.nodes.size(); d.root = root; d.nodes = s.nodes.empty() ? 0 : &s.nodes[0];
+    d.n_data = (int)s.data.size(); d.data = s.data.empty() ? 0 : &s.data[0];
+    d.n_lights = (int)s.lights.size(); d.lights = s.lights.empty() ? 0 : &s.lights[0];
+    d.has_ambient = rt.plAmbient != 0;
+    if (rt.plAmbient) memcpy(d.ambient_flux, rt.plAmbient->flux.rgf, sizeof d.ambient_flux);
+    if (!rt.pcCamera) { snprintf(err, errlen, "RayTracer::pcCamera is null"); return -1; }
+    rt.pcCamera->Describe(d.camera);
+    if (!rt.psSample) { snprintf(err, errlen, "RayTracer::psSample is null"); return -1; }
+    int st = rt.psSample->DeviceSampler();
+    if (st < 0) { snprintf(err, errlen, "this SamplingTile has no device path"); return -1; }
+    d.sampler.type = st;
+    d.sampler.venera = rt.psSample->nVenera;
+    out.qi2.assign(g_BlueNoiseQuasiIndex2, g_BlueNoiseQuasiIndex2 + BLUE_N);
+    out.qi3.assign(g_BlueNoiseQuasiIndex3, g_BlueNoiseQuasiIndex3 + BLUE_N);
+    d.sampler.qindex2 = &out.qi2[0];
+    d.sampler.qindex3 = &out.qi3[0];
+    const double aux[6] = { g_uCamera, g_vCamera, g_uLight, g_vLight, g_uMicroFacet, g_vMicroFacet };
+    memcpy(d.sampler.aux_init, aux, sizeof aux);
+    return 0;
+}
+
+int Image::NewImage(int w, int h, int channels)
+{
+    int64_t n = (int64_t)w * h * channels, old = (int64_t)m_nWidth * m_nHeight * m_nChannels;
+    if (!m_pfImage || n != old) { delete[] m_pfImage; m_pfImage = new float[n]; }
+    m_nWidth = w; m_nHeight = h; m_nChannels = channels;
+    return m_pfImage != 0;
+}
+
+int RayTracer::Render(Image &im, double spp)
+{
+    RtSceneBlob blob;
+    if (rt_flatten(*this, blob, s_err, sizeof s_err)) return -1;
+    if (im.m_nChannels != 3) { snprintf(s_err, sizeof s_err, "Render needs a 3-channel Image"); return -1; }
+    rt_scene *sc = 0;
+    if (rt_scene_upload(&blob.desc, &sc)) { snprintf(s_err, sizeof s_err, "rt_scene_upload: %s", rt_last_error()); return -1; }
+    RtRenderDesc rd;
+    memset(&rd, 0, sizeof rd);
+    rd.width = im.m_nWidth; rd.height = im.m_nHeight; rd.spp = spp;
+    int rc = rt_render(sc, &rd, im.m_pfImage, &stats);
+    if (rc) snprintf(s_err, sizeof s_err, "rt_render: %s", rt_last_error());
+    rt_scene_free(sc);
+    return rc ? -1 : (int)stats.samples;
+}

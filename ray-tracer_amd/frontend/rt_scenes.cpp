@@ -1,0 +1,450 @@
+/*
+ * rt_scenes.cpp -- scene scripts written against the host scene API exactly the way the
+ * reference's drivers write theirs, plus a small text front door for tests and tools.
+ *
+ * Named scenes (the synthetic, deterministic inputs of bench.py and the parity tests):
+ *   S0  the as-checked-in driver scene: TestRayTraceScene (TestScene.cpp:1539-1628) = 41 RNDSPEC
+ *       draws, InitializeCSystem (:1362-1378), MakeModelCSystem(0, 1000) (:1380-1424) -- a 0.5-radius
+ *       neutronium ball and 256 small plastic spheres on the unit sphere --, MakeLightsLorenz
+ *       (:1472-1487), StereographicCamera((0,0,8), 70) (:1593).
+ *   S1  MakeModel(30) (:44-77): the nine-primitive zoo over a floor slab, with MakeLights (:1456-1470)
+ *       (area light + point light, shadows on), same camera.
+ *   S2  DistributedRayTracer's scene (DistributedRayTracing.cpp:56-150): IcosahedronCage in polished
+ *       blue plastic over a floor inside a NOSHADE sky dome, ApertureCamera(1.4, 24, (0,0,9), 35)
+ *       (the commented camera line :128), area + point light, QIndex1(0).
+ * Argument evaluation order where the reference leaves it to the compiler (RandomDouble() calls
+ * as constructor arguments): right to left, which is what both MSVC and g++ do.
+ */
+#include <stdlib.h>
+#include <ctype.h>
+#include <string>
+#include "rt_frontend.h"
+
+/* ------------------------------------------------------------------------------ S0 / S1 ---- */
+static Spectrum random_spectrum()       /* RNDSPEC, TestScene.cpp:11 */
+{
+    double b = RandomDouble(), g = RandomDouble(), r = RandomDouble();
+    return RGBtoSpectrum(DisplayRGB(r, g, b));
+}
+
+static void palette(Spectrum *rgs /*20*/)  /* TestScene.cpp:1566-1581 */
+{
+    rgs[0] = random_spectrum();
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < 20; i++) rgs[i] = random_spectrum();
+    for (int i = 1; i <= 9; i += 2) rgs[i] = g_sCopper;
+}
+
+enum { NLORENZ = 256 };
+static Vector5  s_csystem[NLORENZ];
+static Spectrum s_cscolor[NLORENZ];
+
+static void init_csystem()              /* TestScene.cpp:1362-1378 */
+{
+    Spectrum blue = g_sEqualWhite * 0.5 + g_sBlue * 0.5;
+    for (int i = 0; i < NLORENZ; i++) {
+        double e = RandomDouble(), d = RandomDouble(), c = RandomDouble(), b = RandomDouble(), a = RandomDouble();
+        Vector5 v(a, b, c, d, e);
+        s_csystem[i] = v / v.Norm();
+        s_cscolor[i] = i == 0 ? g_sRed : blue;
+    }
+}
+
+static Solid *model_csystem(int steps)  /* TestScene.cpp:1380-1424 */
+{
+    const double dt = 0.01;
+    while (--steps >= 0) {
+        for (int i = 0; i < NLORENZ; i++) {
+            Vector5 v = s_csystem[i], dv;
+            for (int j = 0; j < 5; j++)
+                dv.rgf[j] = v.rgf[(j + 1) % 5] * v.rgf[(j + 2) % 5] + v.rgf[(j + 4) % 5] * v.rgf[(j + 3) % 5] - 2.0 * v.rgf[(j + 1) % 5] * v.rgf[(j + 4) % 5];
+            for (int j = 0; j < 5; j++)
+                v.rgf[j] += dv.rgf[j] * dt;
+            s_csystem[i] = v / v.Norm();
+        }
+    }
+    Solid *all = new Translate(0.0, 0.0, 0.0, new Scale(0.5, 0.5, 0.5, new Sphere));
+    for (int i = 0; i < NLORENZ; i++) {
+        Vector3 v3(s_csystem[i].x, s_csystem[i].y, s_csystem[i].z);
+        Solid *ps = new Translate(v3 / Norm(v3), new Scale(0.05, 0.05, 0.05, new Sphere));
+        if (i == 0)
+            ps = new Translate(s_csystem[i].x, s_csystem[i].y, s_csystem[i].z, new Scale(0.1, 0.1, 0.1, new Sphere));
+        all = new Union(new Material(0.9, s_cscolor[i], MAT_PLASTIC, ps), all);
+    }
+    return all;
+}
+
+static Solid *model_zoo(double deg, const Spectrum *rgs)     /* MakeModel, TestScene.cpp:44-77 */
+{
+    double a = deg * D_PI / 180.0;
+    Solid *p[9];
+    p[0] = new Translate(-3.0, -3.0, 0.0, new Rotate(0.0, a, 0.0, new Cylinder));
+    p[1] = new Translate(-3.0, 0.0, 0.0, new Rotate(0.0, a, 0.0, new Torus(0.5)));
+    p[2] = new Translate(-3.0, 3.0, 0.0, new Rotate(0.0, a, 0.0, new Intersection(new Sphere, new Hyperboloid2(0.125))));
+    p[3] = new Translate(0.0, -3.0, 0.0, new Rotate(0.0, a, 0.0, new Intersection(new Sphere, new Hyperboloid1(0.125))));
+    p[4] = new Translate(0.0, 0.0, 0.0, new Rotate(0.0, a, 0.0, new Difference(new Icosahedron, new Cone)));
+    p[5] = new Translate(0.0, 3.0, 0.0, new Rotate(0.0, a, 0.0, new Dodecahedron));
+    p[6] = new Translate(3.0, -3.0, 0.0, new Rotate(0.0, a, 0.0, new Scale(1.2, 0.8, 0.8, new Sphere)));
+    p[7] = new Translate(3.0, 0.0, 0.0, new Rotate(0.0, a, 0.0, new Union(new Torus(0.2), new Sphere)));
+    p[8] = new Translate(3.0, 3.0, 0.0, new Rotate(0.0, a, 0.0, new Difference(new Cube, new Scale(0.5, 0.5, 1.2, new Cylinder))));
+    for (int i = 0; i < 9; i++) p[i] = new Material(0.9, rgs[i], MAT_METAL, p[i]);
+    Solid *ps = p[0];
+    for (int i = 1; i < 9; i++) ps = new Union(p[i], ps);
+    ps = new Surface(SURF_BURNISHED, ps);
+    return new Union(ps, new Translate(0.0, 5.25, -10.0, new Scale(12.0, 1.0, 12.0, new Cube)));
+}
+
+static void lights_two(RayTracer *rt)   /* MakeLights, TestScene.cpp:1456-1470 */
+{
+    Spectrum s6500 = BlackBody(6500.0);
+    rt->plAmbient = new AmbientLight(s6500 * 0.02);
+    rt->plPointLights = new AreaLight(1.0, Point3(10.0, -10.0, 10.0), s6500 * 10000.0);
+    rt->plPointLights = new PointLight(Point3(-10.0, -10.0, -10.0), s6500 * 500.0, rt->plPointLights);
+}
+
+static void lights_far(RayTracer *rt)   /* MakeLightsLorenz, TestScene.cpp:1472-1487 */
+{
+    Spectrum s6500 = BlackBody(6500.0);
+    rt->plAmbient = new AmbientLight(s6500 * 0.02);
+    rt->plPointLights = new AreaLight(1.0, Point3(100.0, -100.0, 100.0), s6500 * 1000000.0);
+    rt->plPointLights->nNoShadow = 1;
+}
+
+static void reset_globals()
+{
+    ML_InitializeRandom();
+    g_uCamera = g_vCamera = g_uLight = g_vLight = g_uMicroFacet = g_vMicroFacet = 0.0;
+    BuildQuasiIndex(g_BlueNoiseQuasiIndex2, 2, BLUE_N);
+}
+
+static int build_S0(RayTracer &rt)
+{
+    Spectrum rgs[20];
+    reset_globals();
+    palette(rgs);
+    lights_far(&rt);
+    rt.pcCamera = new StereographicCamera(Point3(+0.0, 0.0, 8.0), 70.0);
+    init_csystem();
+    rt.psModel = model_csystem(1000);
+    return 0;
+}
+
+static int build_S1(RayTracer &rt)
+{
+    Spectrum rgs[20];
+    reset_globals();
+    palette(rgs);
+    lights_two(&rt);
+    rt.pcCamera = new StereographicCamera(Point3(+0.0, 0.0, 8.0), 70.0);
+    rt.psModel = model_zoo(30.0, rgs);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ S2 ---- */
+static Solid *lab_environment(Solid *ps, RayTracer &rt)     /* EnvironmentLab, DistributedRayTracing.cpp:56-77 */
+{
+    Spectrum s6500 = BlackBody(6500.0);
+    double f20 = 0.0 * D_PI / 180.0;
+    rt.plAmbient = new HavercosineLight(s6500 * 0.002, g_sBlack);
+    rt.plPointLights = new AreaLight(1.0, Point3(9.0, -6.5, 12.0), s6500 * 8000.0 * 1.2);
+    rt.plPointLights = new PointLight(Point3(10.0, -10.0, -25.0), s6500 * 1000.0, rt.plPointLights);
+    return MakeUnion(
+        ps,
+        new Translate(0.0, 1.5, -10.0, new Rotate(f20, 0.0, 0.0, new Scale(16.0, 0.1, 16.0, new Material(0.9, g_sEqualWhite, MAT_PLASTIC, new Cube)))),
+        new Scale(1000.0, 1000.0, 1000.0, new Material(0.9, g_sEarthSky * 2.0, MAT_NOSHADE, new HollowSphere)));
+}
+
+static int build_S2(RayTracer &rt)      /* DistributedRayTracer, DistributedRayTracing.cpp:111-150 */
+{
+    reset_globals();
+    FastBlueSamplingTile *tile = new FastBlueSamplingTile;
+    tile->QIndex1(0);
+    rt.psSample = tile;
+    rt.pcCamera = new ApertureCamera(1.4, 9.0 + 15.0, Point3(0.0, +0.0, 9.0), 35.0);
+    double ang = 0.0 * D_PI / 180.0;
+    Solid *ps = MakeUnion(new Translate(+0.0, 0.0, 0.0, new Rotate(0.0, ang, 0.0, IcosahedronCage(0.05, 0.1))));
+    Spectrum blue = (g_sEqualWhite + g_sBlue) * 0.5;
+    ps = new Surface(SURF_POLISHED, 0, new Material(0.7, REFRACT_PYREX, blue, MAT_PLASTIC, 0, ps));
+    rt.psModel = lab_environment(ps, rt);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------- text front door ---- */
+namespace {
+struct Parser {
+    const char *p;
+    std::string err;
+    RayTracer *rt;
+    explicit Parser(const char *s, RayTracer *r) : p(s), rt(r) {}
+    void ws() { while (*p && (isspace((unsigned char)*p))) p++; }
+    bool fail(const std::string &m) { if (err.empty()) err = m + " near '" + std::string(p).substr(0, 24) + "'"; return false; }
+    bool open() { ws(); if (*p == '(') { p++; return true; } return false; }
+    bool close() { ws(); if (*p == ')') { p++; return true; } return fail("expected ')'"); }
+    std::string word()
+    {
+        ws();
+        std::string w;
+        while (*p && !isspace((unsigned char)*p) && *p != '(' && *p != ')') w += *p++;
+        return w;
+    }
+    double num()
+    {
+        ws();
+        char *e;
+        double v = strtod(p, &e);
+        if (e == p) { fail("expected number"); return 0.0; }
+        p = e;
+        return v;
+    }
+    bool peek_open() { ws(); return *p == '('; }
+    bool peek_close() { ws(); return *p == ')'; }
+
+    Spectrum spectrum()
+    {
+        Spectrum s = g_sBlack;
+        if (open()) {
+            std::string w = word();
+            if (w == "scale") { s = spectrum(); double f = num(); s = s * f; }
+            else if (w == "add") { Spectrum a = spectrum(), b = spectrum(); s = a + b; }
+            else if (w == "blackbody") s = BlackBody(num());
+            else if (w == "rgb") { double r = num(), g = num(), b = num(); s = RGBtoSpectrum(DisplayRGB(r, g, b)); }
+            else if (w == "gray") s = RGBtoSpectrum(num());
+            else fail("unknown spectrum form " + w);
+            close();
+            return s;
+        }
+        std::string w = word();
+        const Spectrum *t = rt_spectrum_by_name(w.c_str());
+        if (!t) { fail("unknown spectrum " + w); return s; }
+        return *t;
+    }
+    int luster(const std::string &w)
+    {
+        static const char *n[] = { "noshade", "plastic", "metal", "transparent", "copper", "gold", "iron", "aluminum", "osmium", "silver", "titanium" };
+        for (int i = 0; i < 11; i++) if (w == n[i]) return i;
+        fail("unknown luster " + w);
+        return MAT_PLASTIC;
+    }
+    int rough(const std::string &w)
+    {
+        static const char *n[] = { "", "matte", "burnished", "smooth", "shiny", "polished", "wet" };
+        for (int i = 1; i < 7; i++) if (w == n[i]) return i;
+        fail("unknown roughness " + w);
+        return SURF_MATTE;
+    }
+    TextureMap texture(const std::string &w)
+    {
+        if (w == "none") return 0;
+        static const struct { const char *n; TextureMap f; } t[] = {
+            { "bumpy", Bumpy }, { "microfacets", MicroFacets }, { "microfacets2", MicroFacets2 }, { "wrinkled", Wrinkled }, { "faceted20", Faceted20 },
+            { "dented", Dented }, { "wavy", Wavy }, { "fibers", Fibers }, { "blistered", Blistered }, { "hammered", Hammered },
+            { "tectonic", Tectonic }, { "quasimicrofacet", QuasiMicroFacet } };
+        for (size_t i = 0; i < sizeof t / sizeof t[0]; i++) if (w == t[i].n) return t[i].f;
+        fail("unknown texture " + w);
+        return 0;
+    }
+    Propagator propagator(const std::string &w)
+    {
+        if (w == "none") return 0;
+        if (w == "coloredglass") return ColoredGlass;
+        if (w == "foggy") return Foggy;
+        fail("unknown propagator " + w);
+        return 0;
+    }
+    int children(Solid **v, int maxn)
+    {
+        int n = 0;
+        while (peek_open() && n < maxn) v[n++] = solid();
+        return n;
+    }
+    Solid *solid()
+    {
+        if (!open()) { fail("expected '('"); return 0; }
+        std::string w = word();
+        Solid *r = 0;
+        if (w == "sphere") r = new Sphere;
+        else if (w == "hollowsphere") r = new HollowSphere;
+        else if (w == "cylinder") r = new Cylinder;
+        else if (w == "cone") r = new Cone;
+        else if (w == "conefx") r = new ConeFX;
+        else if (w == "coneunit") r = new ConeUnit;
+        else if (w == "paraboloid") r = new Paraboloid;
+        else if (w == "hyperboloid1") r = new Hyperboloid1(num());
+        else if (w == "hyperboloid2") r = new Hyperboloid2(num());
+        else if (w == "conehypercylinder") r = new ConeHyperCylinder(num());
+        else if (w == "quadric") { double P = num(), Q = num(), R = num(); int c = (int)num(); r = new Quadric(P, Q, R, c); }
+        else if (w == "cube") r = new Cube;
+        else if (w == "tetrahedron") r = new Tetrahedron;
+        else if (w == "octahedron") r = new Octahedron;
+        else if (w == "dodecahedron") r = new Dodecahedron;
+        else if (w == "icosahedron") r = new Icosahedron;
+        else if (w == "prism") r = new Prism((int)num());
+        else if (w == "fibonacci") r = new Fibonacci((int)num());
+        else if (w == "slab") r = new Slab;
+        else if (w == "torus") r = new Torus(num());
+        else if (w == "null") r = new NullSolid;
+        else if (w == "translate") { double x = num(), y = num(), z = num(); r = new Translate(x, y, z, solid()); }
+        else if (w == "scale") { double x = num(), y = num(), z = num(); r = new Scale(x, y, z, solid()); }
+        else if (w == "rotate") { double x = num(), y = num(), z = num(); r = new Rotate(x, y, z, solid()); }
+        else if (w == "rotateaxis") { double x = num(), y = num(), z = num(), a = num(); r = new Rotate(Vector3(x, y, z), a, solid()); }
+        else if (w == "rotatefromto") { double a = num(), b = num(), c = num(), x = num(), y = num(), z = num(); r = new Rotate(Vector3(a, b, c), Vector3(x, y, z), solid()); }
+        else if (w == "union") { Solid *a = solid(), *b = solid(); r = new Union(a, b); }
+        else if (w == "topunion") { Solid *a = solid(), *b = solid(); r = new TopUnion(a, b); }
+        else if (w == "intersection") { Solid *a = solid(), *b = solid(); r = new Intersection(a, b); }
+        else if (w == "difference") { Solid *a = solid(), *b = solid(); r = new Difference(a, b); }
+        else if (w == "makeunion" || w == "maketopunion" || w == "makeintersection") {
+            Solid *v[64];
+            int n = children(v, 64);
+            r = w == "makeintersection" ? rt_make_intersection(v, n) : rt_make_union(v, n, w == "maketopunion");
+        }
+        else if (w == "angularclip") { double a = num(), b = num(); r = new AngularClip(a, b, solid()); }
+        else if (w == "boundingbox") r = new BoundingBox(solid());
+        else if (w == "material") {
+            /* (material density refr|auto color luster texture propagator child) */
+            double d = num();
+            ws();
+            bool autoN = false;
+            double n = 0.0;
+            if (isalpha((unsigned char)*p)) { std::string a = word(); autoN = (a == "auto"); if (!autoN) fail("expected refractive index or auto"); }
+            else n = num();
+            Spectrum c = spectrum();
+            int l = luster(word());
+            TextureMap t = texture(word());
+            Propagator pr = propagator(word());
+            Solid *ch = solid();
+            Material *m = autoN ? new Material(d, c, l, t, ch) : new Material(d, n, c, l, pr, ch);
+            if (autoN) m->Propagate = pr; else m->Texture = t;
+            r = m;
+        }
+        else if (w == "surface") { int ro = rough(word()); TextureMap t = texture(word()); r = new Surface(ro, t, solid()); }
+        else if (w == "cuboid") { double a = num(), x = num(), y = num(), z = num(); r = Cuboid(a, x, y, z); }
+        else if (w == "cylinderfromto") { double a = num(), b = num(), c = num(), x = num(), y = num(), z = num(), rr = num(); r = CylinderFromTo(Point3(a, b, c), Point3(x, y, z), rr); }
+        else if (w == "tetrahedroncage") { double a = num(), b = num(); r = TetrahedronCage(a, b); }
+        else if (w == "hexahedroncage") { double a = num(), b = num(); r = HexahedronCage(a, b); }
+        else if (w == "octahedroncage") { double a = num(), b = num(); r = OctahedronCage(a, b); }
+        else if (w == "icosahedroncage") { double a = num(), b = num(); r = IcosahedronCage(a, b); }
+        else if (w == "dodecahedroncage") { double a = num(), b = num(); r = DodecahedronCage(a, b); }
+        else if (w == "diskoid") r = Diskoid(num());
+        else if (w == "rodoid") r = Rodoid(num());
+        else if (w == "squareoid") r = Squareoid(num());
+        else if (w == "knoboid") { double a = num(), z = num(); r = Knoboid(a, z); }
+        else if (w == "knoboid2") { double a = num(), z = num(); r = Knoboid2(a, z); }
+        else if (w == "hyperboloidoid") { double a = num(), b = num(), z = num(); r = Hyperboloidoid(a, b, z); }
+        else if (w == "slaboid") { double x = num(), y = num(), z = num(), a = num(); r = Slaboid(x, y, z, a); }
+        else fail("unknown solid " + w);
+        close();
+        return r;
+    }
+    bool scene()
+    {
+        if (!open() || word() != "scene") return fail("expected (scene ...)");
+        while (open()) {
+            std::string w = word();
+            if (w == "model") rt->psModel = solid();
+            else if (w == "ambient") rt->plAmbient = new AmbientLight(spectrum());
+            else if (w == "pointlight") {
+                double x = num(), y = num(), z = num();
+                Spectrum s = spectrum();
+                PointLight *pl = new PointLight(Point3(x, y, z), s, rt->plPointLights);
+                if (!peek_close() && word() == "noshadow") pl->nNoShadow = 1;
+                rt->plPointLights = pl;
+            }
+            else if (w == "arealight") {
+                double d = num(), x = num(), y = num(), z = num();
+                Spectrum s = spectrum();
+                PointLight *pl = new AreaLight(d, Point3(x, y, z), s, rt->plPointLights);
+                if (!peek_close() && word() == "noshadow") pl->nNoShadow = 1;
+                rt->plPointLights = pl;
+            }
+            else if (w == "camera") {
+                std::string k = word();
+                if (k == "aperture") { double fs = num(), fd = num(), x = num(), y = num(), z = num(), f = num(); rt->pcCamera = new ApertureCamera(fs, fd, Point3(x, y, z), f); }
+                else {
+                    double x = num(), y = num(), z = num(), f = num();
+                    if (k == "stereographic") rt->pcCamera = new StereographicCamera(Point3(x, y, z), f);
+                    else if (k == "perspective") rt->pcCamera = new PerspectiveCamera(Point3(x, y, z), f);
+                    else if (k == "orthographic") rt->pcCamera = new OrthographicCamera(Point3(x, y, z), f);
+                    else fail("unknown camera " + k);
+                }
+            }
+            else if (w == "sampler") {
+                std::string k = word();
+                if (k == "test") rt->psSample = new TestSamplingTile;
+                else if (k == "fastblue") { rt->psSample = new FastBlueSamplingTile; if (!peek_close()) rt->psSample->QIndex1((int)num()); }
+                else fail("unknown sampler " + k);
+            }
+            else if (w == "aux") { g_uCamera = num(); g_vCamera = num(); g_uLight = num(); g_vLight = num(); g_uMicroFacet = num(); g_vMicroFacet = num(); }
+            else fail("unknown scene item " + w);
+            if (!err.empty() || !close()) return false;
+        }
+        return close() && err.empty();
+    }
+};
+}
+
+/* ------------------------------------------------------------------------ C entry points ---- */
+struct rtf_scene {
+    RayTracer   rt;
+    RtSceneBlob blob;
+};
+static char s_scene_err[512];
+
+extern "C" const char *rtf_last_error() { return s_scene_err[0] ? s_scene_err : rt_frontend_last_error(); }
+
+/* spec: "S0" | "S1" | "S2" | "(scene ...)".  sampler: "", "test" or "fastblue" overrides the scene's tile.
+   optimize != 0 calls psModel->Optimize() before flattening (what every reference driver does). */
+extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int optimize)
+{
+    rtf_scene *s = new rtf_scene;
+    s_scene_err[0] = 0;
+    std::string name(spec);
+    int rc = 0;
+    if (name == "S0") rc = build_S0(s->rt);
+    else if (name == "S1") rc = build_S1(s->rt);
+    else if (name == "S2") rc = build_S2(s->rt);
+    else {
+        reset_globals();
+        Parser ps(spec, &s->rt);
+        if (!ps.scene()) { snprintf(s_scene_err, sizeof s_scene_err, "scene text: %s", ps.err.c_str()); delete s; return 0; }
+    }
+    if (rc) { delete s; return 0; }
+    if (sampler && !strcmp(sampler, "test")) s->rt.psSample = new TestSamplingTile;
+    else if (sampler && !strcmp(sampler, "fastblue") && !(s->rt.psSample && s->rt.psSample->DeviceSampler() == RT_SAMPLER_FASTBLUE)) s->rt.psSample = new FastBlueSamplingTile;
+    if (!s->rt.psSample) s->rt.psSample = new TestSamplingTile;
+    if (!s->rt.pcCamera) s->rt.pcCamera = new StereographicCamera(Point3(0.0, 0.0, 8.0), 70.0);
+    if (optimize && s->rt.psModel) s->rt.psModel = s->rt.psModel->Optimize();
+    if (rt_flatten(s->rt, s->blob, s_scene_err, sizeof s_scene_err)) { delete s; return 0; }
+    return s;
+}
+extern "C" const RtSceneDesc *rtf_scene_desc(rtf_scene *s) { return &s->blob.desc; }
+extern "C" void rtf_scene_free(rtf_scene *s) { delete s; }
+
+/* RayTracer::Render through the front end (scene -> flatten -> C ABI -> planes) */
+extern "C" int rtf_scene_render(rtf_scene *s, int width, int height, double spp, float *planes, RtStats *stats)
+{
+    Image im;
+    im.NewImage(width, height, 3);
+    int n = s->rt.Render(im, spp);
+    if (n < 0) { snprintf(s_scene_err, sizeof s_scene_err, "%s", rt_frontend_last_error()); return -1; }
+    memcpy(planes, im.m_pfImage, sizeof(float) * 3 * (size_t)width * height);
+    if (stats) *stats = s->rt.stats;
+    return n;
+}
+
+/* GetExtent() of the scene root and of a scene given as text: 6 doubles */
+extern "C" int rtf_extent(const char *solid_text, double *out6)
+{
+    RayTracer rt;
+    Parser ps(solid_text, &rt);
+    Solid *sd = ps.solid();
+    if (!sd || !ps.err.empty()) { snprintf(s_scene_err, sizeof s_scene_err, "solid text: %s", ps.err.c_str()); return -1; }
+    Extent e = sd->GetExtent();
+    out6[0] = e.pMin.x; out6[1] = e.pMin.y; out6[2] = e.pMin.z; out6[3] = e.pMax.x; out6[4] = e.pMax.y; out6[5] = e.pMax.z;
+    return 0;
+}
+
+extern "C" void rtf_random_double(unsigned x, unsigned c, int n, double *out)
+{
+    ML_InitializeRandom(x, c);
+    for (int i = 0; i < n; i++) out[i] = RandomDouble();
+}
