@@ -1,0 +1,1020 @@
+/*
+ * rt_core.hip.h -- device functions of the render path (gfx950): double-precision geometry, root
+ * finders, primitive intersection, the per-ray CSG stack machine, normal transforms + bump noise,
+ * Fresnel / BRDF / propagators.  Arithmetic follows the reference expression by expression
+ * (file:line cited at each function) and the translation unit is compiled with -ffp-contract=off so
+ * that results round exactly as on the host: +,-,*,/ and sqrt are IEEE-exact in f64 and f32 on CDNA4;
+ * only exp/acos/cos/sin (ColoredGlass, the three-real-root branch of the torus cubic, Wavy) go through
+ * the device math library and may differ from glibc in the last ulp.
+ *
+ * No MFMA: nothing here is a dense contraction.  The hot loop is branchy f64 VALU work over a scene
+ * that fits in L2; hit lists live in per-lane private memory (scratch is lane-interleaved by the
+ * hardware, so uniform indices coalesce).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt_device.h"
+
+#define RT_DEV __device__ __forceinline__
+#define RT_DEVN __device__ __noinline__
+
+struct D3 { double x, y, z; };
+RT_DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV D3 operator+(const D3 &a, const D3 &b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV D3 operator-(const D3 &a, const D3 &b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV D3 operator-(const D3 &a) { return d3(-a.x, -a.y, -a.z); }
+RT_DEV D3 operator*(const D3 &a, double f) { return d3(a.x * f, a.y * f, a.z * f); }
+RT_DEV D3 operator/(const D3 &a, double f) { return d3(a.x / f, a.y / f, a.z / f); }
+RT_DEV double dot(const D3 &u, const D3 &v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+RT_DEV D3 cross(const D3 &u, const D3 &v) { return d3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+RT_DEV double norm(const D3 &v) { return sqrt(dot(v, v)); }
+RT_DEV D3 normalize(const D3 &v) { return v / norm(v); }
+/* Matrix3 * Vector3 (Affine.h:191-205) and CoVector3 * Matrix3 (Affine.h:286-292), m row major */
+RT_DEV D3 mat_vec(const double *m, const D3 &v)
+{
+    return d3(v.x * m[0] + v.y * m[1] + v.z * m[2], v.x * m[3] + v.y * m[4] + v.z * m[5], v.x * m[6] + v.y * m[7] + v.z * m[8]);
+}
+RT_DEV D3 covec_mat(const D3 &c, const double *m)
+{
+    return d3(c.x * m[0] + c.y * m[3] + c.z * m[6], c.x * m[1] + c.y * m[4] + c.z * m[7], c.x * m[2] + c.y * m[5] + c.z * m[8]);
+}
+
+struct DRay { D3 org, dir; };
+RT_DEV D3 ray_at(const DRay &r, double t) { return r.org + r.dir * t; }
+
+struct Spec { float v[RT_NSPEC]; };
+RT_DEV Spec spec_const(float f) { Spec s; for (int i = 0; i < RT_NSPEC; i++) s.v[i] = f; return s; }
+RT_DEV Spec spec_load(const float *p) { Spec s; for (int i = 0; i < RT_NSPEC; i++) s.v[i] = p[i]; return s; }
+RT_DEV Spec operator+(const Spec &a, const Spec &b) { Spec r; for (int i = 0; i < RT_NSPEC; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+RT_DEV Spec operator*(const Spec &a, const Spec &b) { Spec r; for (int i = 0; i < RT_NSPEC; i++) r.v[i] = a.v[i] * b.v[i]; return r; }
+RT_DEV Spec operator*(const Spec &a, double f) { Spec r; for (int i = 0; i < RT_NSPEC; i++) r.v[i] = (float)((double)a.v[i] * f); return r; }
+RT_DEV Spec spec_div(const Spec &a, double f) { Spec r; if (f != 0.0) f = 1.0 / f; for (int i = 0; i < RT_NSPEC; i++) r.v[i] = (float)((double)a.v[i] * f); return r; }
+RT_DEV bool spec_is_black(const Spec &a) { for (int i = 0; i < RT_NSPEC; i++) if (a.v[i] != 0.0f) return false; return true; }
+
+#define RT_PI    3.14159265358979323846264338327950288419716939937510
+#define RT_SQRT3 1.73205080756887729352744634150587236694280525381038
+
+/* ================================================================== root finders (Solids.cpp:277-561) */
+RT_DEV int solve_linear(double *r, double a, double b)
+{
+    if (a == 0.0) {
+        if (b == 0.0) { r[0] = 0.0; return 1; }
+        return 0;
+    }
+    r[0] = -b / a;
+    return 1;
+}
+
+RT_DEV int solve_quadratic(double *r, double a, double b, double c)
+{
+    if (a == 0.0) return solve_linear(r, b, c);
+    double disc = b * b - 4.0 * a * c;
+    if (disc <= 0.0) {
+        if (disc == 0.0) { r[0] = r[1] = -b / (a + a); return 2; }
+        return 0;
+    }
+    disc = sqrt(disc);
+    if (a < 0.0) { a = -a; b = -b; c = -c; }
+    if (b > 0.0) {
+        r[0] = (-b - disc) / (a + a);
+        r[1] = (c + c) / (-b - disc);
+    } else {
+        r[1] = (-b + disc) / (a + a);
+        r[0] = (c + c) / (-b + disc);
+    }
+    return 2;
+}
+
+__device__ double cube_root(double x)
+{
+    const double c2 = 1.259921049894873164767210607278228350570251, c4 = 1.587401051968199474751705639272308260391493;
+    const double c2i = 0.7937005259840997373758528196361541301957467, c4i = 0.6299605249474365823836053036391141752851257;
+    if (x == 0) return x;
+    int sign = 1, e, rem;
+    if (!(x > 0)) { sign = -1; x = -x; }
+    double z = x;
+    x = frexp(x, &e);
+    x = (((((1.3584464340920900529734e-1) * x - (6.3986917220457538402318e-1)) * x + (1.2875551670318751538055e0)) * x
+          - (1.4897083391357284957891e0)) * x + (1.3304961236013647092521e0)) * x + (3.7568280825958912391243e-1);
+    if (e >= 0) {
+        rem = e; e /= 3; rem -= 3 * e;
+        if (rem == 1) x *= c2; else if (rem == 2) x *= c4;
+    } else {
+        e = -e; rem = e; e /= 3; rem -= 3 * e;
+        if (rem == 1) x *= c2i; else if (rem == 2) x *= c4i;
+        e = -e;
+    }
+    x = ldexp(x, e);
+    x -= (x - (z / (x * x))) / 3.0;
+    x -= (x - (z / (x * x))) / 3.0;
+    x -= (x - (z / (x * x))) / 3.0;
+    return sign < 0 ? -x : x;
+}
+
+__device__ int solve_cubic(double *r, double a, double b, double c, double d)
+{
+    if (a == 0.0) return solve_quadratic(r, b, c, d);
+    double A = b / a, B = c / a, C = d / a;
+    double yi2 = 0.5 * (A * (2.0 * A * A - 9.0 * B) + 27.0 * C);
+    double ypi3 = 3.0 * B - A * A;
+    double disc = ypi3 * ypi3 * ypi3 + yi2 * yi2;
+    double S, S3, T, U, V, fc, fs;
+    if (disc > 0.0) {
+        U = cube_root(fabs(yi2) + sqrt(disc));
+        if (yi2 > 0.0) U = -U;
+        V = -ypi3 / U;
+        r[0] = (U + V - A) * 1.0 / 3.0;
+        return 1;
+    }
+    S = sqrt(-ypi3);
+    S3 = S * S * S;
+    bool one = false;
+    if (yi2 >= S3) {
+        if (yi2 > S3) one = true;
+        fc = 1.0; fs = 0.0;
+    } else if (yi2 <= -S3) {
+        if (yi2 < -S3) one = true;
+        fc = 0.5; fs = 1.5;
+    } else {
+        T = yi2 / S3;
+        double th = acos(T) / 3.0;
+        fc = cos(th);
+        fs = RT_SQRT3 * sin(th);
+    }
+    if (!one) {
+        r[0] = (-2.0 * S * fc - A) * 1.0 / 3.0;
+        r[1] = (S * (fc - fs) - A) * 1.0 / 3.0;
+        r[2] = (S * (fc + fs) - A) * 1.0 / 3.0;
+        return 3;
+    }
+    T = yi2 / S3;
+    U = cube_root(T + sqrt(T * T - 1.0));
+    r[0] = (-S * (U + 1.0 / U) - A) * 1.0 / 3.0;
+    return 1;
+}
+
+__device__ int solve_quartic(double *r, double a, double b, double c, double d, double e)
+{
+    if (a == 0.0) return solve_cubic(r, b, c, d, e);
+    double A = b / a, B = c / a, C = d / a, D = e / a;
+    double P = B, Q = A * C - 4.0 * D, R = D * (A * A - 4.0 * B) + C * C;
+    double cr[3];
+    (void)solve_cubic(cr, 1.0, P, Q, R);
+    double y = cr[0];
+    double EE = 0.25 * A * A - B - y;
+    double FF = 0.25 * y * y - D;
+    double EF = -0.5 * A * y - C;
+    double E = EE < 0.0 ? 0.0 : sqrt(EE);
+    double F = FF < 0.0 ? 0.0 : sqrt(FF);
+    if (EF < 0.0) F = -F;
+    double G = 0.5 * A + E, g = 0.5 * A - E, H, h;
+    if (y * F >= 0.0) {
+        h = -0.5 * y - F;
+        if (h != 0.0) H = D / h; else H = -0.5 * y + F;
+    } else {
+        H = -0.5 * y + F;
+        h = D / H;
+    }
+    int n = solve_quadratic(r, 1.0, G, H);
+    n += solve_quadratic(r + n, 1.0, g, h);
+    for (int j = 1; j < n; j++) {
+        double x = r[j];
+        int i;
+        for (i = j - 1; i >= 0 && x < r[i]; --i) r[i + 1] = r[i];
+        r[i + 1] = x;
+    }
+    return n;
+}
+
+/* ================================================================== per-ray hit storage */
+struct HitRec {
+    double   t;
+    D3       n;
+    uint32_t leaf_affine;   /* index + 1, 0 = none */
+    uint16_t surf, mat;
+    uint16_t prim;          /* primitive index, 0xFFFF = AngularClip wedge */
+    uint8_t  ntex;
+    uint8_t  tex[RT_MAX_TEX];
+};
+
+struct Arena {              /* private (scratch) memory: lane-interleaved, uniform indices coalesce */
+    HitRec   h[RT_ARENA];
+    uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
+    int32_t  l_tag[RT_LIST_STACK];
+    int      nlist;
+    int      top;           /* first free hit slot */
+    int      overflow;
+};
+
+/* HitWork (Solids.h:47-58): up to 4 roots; slot [-1] is addressable */
+struct Work {
+    double r[6];
+    D3     n[6];
+    int    count;
+    int    inside_inf;
+    double eps;
+};
+#define WR(w, i) (w).r[(i) + 1]
+#define WN(w, i) (w).n[(i) + 1]
+
+RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; for (int i = 0; i < 6; i++) { w.r[i] = 0.0; w.n[i] = d3(0, 0, 0); } }
+
+/* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
+__device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
+{
+    int first, origin_inside;
+    for (first = 0; first < w.count; first++)
+        if (WR(w, first) >= 0.0) break;
+    origin_inside = (first & 1) ^ w.inside_inf;
+    bool far_first = (w.count == 0) || (first >= w.count) || (WR(w, first) > w.eps);    /* Q10 */
+    if (origin_inside && far_first) {
+        --first;
+        WR(w, first) = 0.0;
+        WN(w, first) = d3(0.0, 0.0, 0.0);
+    }
+    if ((w.count - first) >= 2 && WR(w, first) == 0.0 && WR(w, first + 1) < w.eps) {
+        first += 2;
+    } else if ((w.count - first) && WR(w, first) < w.eps) {
+        WR(w, first) = 0.0;
+        WN(w, first) = d3(0.0, 0.0, 0.0);
+    }
+    int nout = w.count - first;
+    if (nout <= 0) return;
+    if (A.top + nout > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
+    /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
+    int inside = w.inside_inf;
+    for (int i = w.count - 1; i >= first; --i) {
+        HitRec &h = A.h[A.top + (i - first)];
+        h.t = WR(w, i);
+        h.n = WN(w, i);
+        h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.mat = inside ? 1 : 0;
+        h.surf = (h.t > 0.0) ? 1 : 0;
+        h.prim = prim;
+        h.ntex = 0;
+        inside = !inside;
+    }
+    A.l_start[A.nlist] = (uint16_t)A.top;
+    A.l_count[A.nlist] = (uint16_t)nout;
+    A.l_tag[A.nlist] = tag;
+    A.nlist++;
+    A.top += nout;
+}
+
+/* ClipPlane, Solids.cpp:232-273 */
+RT_DEV int clip_plane(const DRay &ray, const D3 &nrm, Work &w, int do_clip, double pn)
+{
+    double B, C, t = 0.0;
+    if (do_clip && w.count == 0) return 0;
+    B = dot(nrm, ray.dir);
+    C = dot(nrm, ray.org) - pn;
+    if (B != 0.0) t = -C / B;
+    if (!do_clip) {
+        w.count = 1;
+        WR(w, 0) = 0.0;
+        w.inside_inf = 1;
+    }
+    w.inside_inf &= (B < 0.0) ? 1 : 0;
+    if (B < 0.0) {
+        if (w.count == 2 && WR(w, 1) <= t) {
+            w.count = 0;
+        } else if (WR(w, 0) < t) {
+            WR(w, 0) = t;
+            WN(w, 0) = nrm;
+        }
+    } else if (B > 0.0) {
+        if (t <= WR(w, 0)) {
+            w.count = 0;
+        } else if (w.count == 1 || t < WR(w, 1)) {
+            w.count = 2;
+            WR(w, 1) = t;
+            WN(w, 1) = nrm;
+        }
+    } else if (C > 0.0)
+        w.count = 0;
+    return w.count;
+}
+
+/* Extent::TestIntersection, Solids.cpp:1533-1572 (reference semantics, used by BoundingBox nodes and the torus) */
+RT_DEV int extent_test(const double *lo, const double *hi, const DRay &ray)
+{
+    double t0 = 0.0, t1 = RT_INFINITY, tmin = 0.0, tmax = 0.0;
+    const double o[3] = { ray.org.x, ray.org.y, ray.org.z }, dd[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+    for (int i = 0; i < 3; i++) {
+        double B = dd[i];
+        double cmin = +lo[i] - o[i];
+        double cmax = -hi[i] + o[i];
+        if (B != 0.0) { tmin = +cmin / B; tmax = -cmax / B; }
+        if (B < 0.0) {
+            if (t1 < tmax || cmin > 0.0 || t0 >= tmin) return 0;
+            if (t0 < tmax) t0 = tmax;
+            if (t1 > tmin) t1 = tmin;
+        } else if (B > 0.0) {
+            if (t1 < tmin || cmax > 0.0 || t0 >= tmax) return 0;
+            if (t0 < tmin) t0 = tmin;
+            if (t1 > tmax) t1 = tmax;
+        } else if (cmin > 0.0 || cmax > 0.0)
+            return 0;
+    }
+    return 1;
+}
+
+/* this build's culling test: does the world ray, t in [0, tmax], touch the (padded, conservative) box? */
+RT_DEV bool cull_box_hit(const RtBox &b, const DRay &ray, double tmax)
+{
+    double t0 = 0.0, t1 = tmax;
+    const double o[3] = { ray.org.x, ray.org.y, ray.org.z }, dd[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+    for (int i = 0; i < 3; i++) {
+        if (dd[i] != 0.0) {
+            double inv = 1.0 / dd[i];
+            double ta = (b.lo[i] - o[i]) * inv, tb = (b.hi[i] - o[i]) * inv;
+            double tn = fmin(ta, tb), tf = fmax(ta, tb);
+            /* two roundings (reciprocal, product): widen by a few ulps so the test stays conservative */
+            tn -= fabs(tn) * 4e-16; tf += fabs(tf) * 4e-16;
+            t0 = fmax(t0, tn); t1 = fmin(t1, tf);
+        } else if (o[i] < b.lo[i] || o[i] > b.hi[i])
+            return false;
+    }
+    return t0 <= t1;
+}
+
+/* ================================================================== primitives */
+__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag)     /* Solids.cpp:325-358 */
+{
+    Work w;
+    work_init(w);
+    const D3 &d = ray.dir, &o = ray.org;
+    const double P = q.p[0], Q = q.p[1], R = q.p[2];
+    double a = d.x * d.x + d.y * d.y + d.z * d.z * P;
+    double b = 2.0 * (d.x * o.x + d.y * o.y + d.z * o.z * P) + d.z * Q;
+    double c = o.x * o.x + o.y * o.y + o.z * o.z * P + o.z * Q + R;
+    w.count = solve_quadratic(&WR(w, 0), a, b, c);
+    for (int i = 0; i < w.count; i++) {
+        D3 p = ray_at(ray, WR(w, i));
+        WN(w, i) = d3(p.x, p.y, p.z * P + 0.5 * Q);
+    }
+    if (q.i0 == 1) {
+        clip_plane(ray, d3(0.0, 0.0, 1.0), w, 1, 1.0);
+        clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
+    }
+    if (q.i0 == -1) { a = -a; b = -b; c = -c; }
+    w.inside_inf = (a < 0.0) ? 1 : 0;
+    hit_list(w, A, tag, prim, q.leaf_affine);
+}
+
+__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag)   /* Solids.cpp:769-781 */
+{
+    Work w;
+    work_init(w);
+    const double *pl = planes + 3 * (size_t)p.plane0;
+    int n = clip_plane(ray, d3(pl[0], pl[1], pl[2]), w, 0, 1.0);
+    for (int i = 1; n && i < p.i0; i++)
+        n = clip_plane(ray, d3(pl[3 * i], pl[3 * i + 1], pl[3 * i + 2]), w, 1, 1.0);
+    hit_list(w, A, tag, prim, p.leaf_affine);
+}
+
+__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag)        /* Solids.cpp:859-869 */
+{
+    Work w;
+    work_init(w);
+    int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
+    if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
+    hit_list(w, A, tag, prim, p.leaf_affine);
+}
+
+__device__ void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
+{
+    const double rm = tp.p[0];
+    const double lo[3] = { -1.0 - rm, -1.0 - rm, -rm }, hi[3] = { 1.0 + rm, 1.0 + rm, rm };
+    if (!extent_test(lo, hi, ray)) return;
+    Work w;
+    work_init(w);
+    double fT = norm(ray.org - d3(0.0, 0.0, 0.0)) - 1.0 - rm - 0.1;
+    double fS = norm(ray.dir);
+    D3 d = ray.dir, o = ray.org;
+    if (fT >= 0.0) {
+        d = d / fS;
+        o = o + d * fT;
+    } else {
+        fT = 0.0;
+        d = d / fS;
+    }
+    double r2 = rm * rm;
+    double f0 = dot(d, d);
+    double f1 = o.x * d.x + o.y * d.y + o.z * d.z;
+    double f2 = o.x * o.x + o.y * o.y + o.z * o.z;
+    double a = f0 * f0;
+    double b = 4.0 * f0 * f1;
+    double c = 2.0 * f0 * (f2 - r2 - 1.0) + 4.0 * f1 * f1 + 4.0 * d.z * d.z;
+    double dd = 4.0 * (f2 - r2 - 1.0) * f1 + 8.0 * o.z * d.z;
+    double e = (f2 - r2 - 1) * (f2 - r2 - 1.0) - 4.0 * (r2 - o.z * o.z);
+    w.count = solve_quartic(&WR(w, 0), a, b, c, dd, e);
+    double db = 4.0 * a, dc = 3.0 * b, ddd = 2.0 * c, de = dd;
+    for (int i = 0; i < w.count; i++) {
+        double x = WR(w, i);
+        x = x - (e + x * (dd + x * (c + x * (b + x * a)))) / (de + x * (ddd + x * (dc + x * db)));
+        x = x - (e + x * (dd + x * (c + x * (b + x * a)))) / (de + x * (ddd + x * (dc + x * db)));
+        WR(w, i) = x;
+    }
+    for (int i = 0; i < w.count; i++) {
+        double x = o.x + d.x * WR(w, i), y = o.y + d.y * WR(w, i), z = o.z + d.z * WR(w, i);
+        double ax = sqrt(x * x + y * y);
+        WN(w, i) = d3(x - x / ax, y - y / ax, z);
+    }
+    if (fT >= 0.0) {
+        for (int i = 0; i < w.count; i++)
+            WR(w, i) = (WR(w, i) + fT) / fS;
+    }
+    w.inside_inf = 0;
+    w.eps *= 10.0;
+    hit_list(w, A, tag, prim, tp.leaf_affine);
+}
+
+/* ================================================================== CSG merge (Solids.cpp:987-1058) */
+enum { MERGE_MAX = 0, MERGE_MIN = 1, MERGE_DIFF = 2 };
+RT_DEV uint16_t mat_op(int op, uint16_t l, uint16_t r, const RtMaterialDev *mats)
+{
+    double dl = mats[l].density, dr = mats[r].density;
+    if (op == MERGE_MAX) return dl > dr ? l : r;
+    if (op == MERGE_MIN) return dl < dr ? l : r;
+    return dr <= 0.0 ? l : (uint16_t)0;
+}
+
+/* merge the two top lists (left below right, contiguous) into one at the left list's place */
+__device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
+{
+    int li = A.nlist - 2, ri = A.nlist - 1;
+    int ls = A.l_start[li], lc = A.l_count[li], rs = A.l_start[ri], rc = A.l_count[ri];
+    int out = A.top, nout = 0;
+    if (out + lc + rc > RT_ARENA) { A.overflow = 1; A.nlist -= 1; A.l_tag[li] = tag; A.top = rs; return; }
+    int il = 0, ir = 0;
+    uint16_t ml = 0, mr = 0;
+    double prev = mats[0].density;
+    while (il < lc || ir < rc) {
+        bool take_left = (ir >= rc) || (il < lc && A.h[ls + il].t <= A.h[rs + ir].t);
+        if (take_left) {
+            if (ir < rc && A.h[ls + il].t == A.h[rs + ir].t) { mr = A.h[rs + ir].mat; ir++; }
+            ml = A.h[ls + il].mat;
+            uint16_t m = mat_op(op, ml, mr, mats);
+            double dm = mats[m].density;
+            if (dm != prev) { prev = dm; A.h[out + nout] = A.h[ls + il]; A.h[out + nout].mat = m; nout++; }
+            il++;
+        } else {
+            mr = A.h[rs + ir].mat;
+            uint16_t m = mat_op(op, ml, mr, mats);
+            double dm = mats[m].density;
+            if (dm != prev) { prev = dm; A.h[out + nout] = A.h[rs + ir]; A.h[out + nout].mat = m; nout++; }
+            ir++;
+        }
+    }
+    if (nout == 1 && A.h[out].t == 0.0 && mats[A.h[out].mat].density == 0.0) nout = 0;     /* Solids.cpp:1053-1056 */
+    for (int i = 0; i < nout; i++) A.h[ls + i] = A.h[out + i];
+    A.nlist -= 2;
+    A.top = ls;
+    if (nout > 0) {
+        A.l_start[A.nlist] = (uint16_t)ls; A.l_count[A.nlist] = (uint16_t)nout; A.l_tag[A.nlist] = tag;
+        A.nlist++;
+        A.top = ls + nout;
+    }
+}
+
+RT_DEV bool top_is(const Arena &A, int tag) { return A.nlist > 0 && A.l_tag[A.nlist - 1] == tag; }
+RT_DEV bool second_is(const Arena &A, int tag) { return A.nlist > 1 && A.l_tag[A.nlist - 2] == tag; }
+RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.l_start[A.nlist]; }
+
+/* ================================================================== the per-ray stack machine
+ * Evaluates psModel->Intersect(ray) (RayTracer2020.h:72): returns the hit list as [start, start+count)
+ * in the arena.  tmax bounds the culling tests only (shadow rays stop at t = 1, Shade.cpp:328). */
+__device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tmax, Arena &A, int &start)
+{
+    DRay rs[RT_MAX_AFFINE_DEPTH + 1];
+    int depth = 0;
+    rs[0] = wray;
+    A.nlist = 0; A.top = 0; A.overflow = 0;
+    int pc = 0;
+    for (;;) {
+        const RtInstr in = S.prog[pc];
+        pc++;
+        switch (in.op) {
+        case OP_END:
+            goto done;
+        case OP_BOUND:
+            if (!cull_box_hit(S.boxes[in.a], wray, tmax)) pc = in.b;
+            break;
+        case OP_REFBOX:
+            if (!extent_test(S.boxes[in.a].lo, S.boxes[in.a].hi, rs[depth])) pc = in.b;
+            break;
+        case OP_PUSH_AFFINE: {                                  /* AffineSolid::Intersect, Solids.cpp:899-913 */
+            const RtAffine &a = S.affines[in.a];
+            DRay nr;
+            nr.dir = mat_vec(a.minv, rs[depth].dir);
+            nr.org = mat_vec(a.minv, rs[depth].org - d3(a.tr[0], a.tr[1], a.tr[2]));
+            depth++;
+            rs[depth] = nr;
+            break;
+        }
+        case OP_POP_AFFINE:
+            depth--;
+            break;
+        case OP_QUADRIC: quadric_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
+        case OP_POLY:    poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, rs[depth], A, in.tag); break;
+        case OP_SLAB:    slab_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
+        case OP_TORUS:   torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
+        case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
+            if (!top_is(A, 2 * in.b)) break;
+            int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
+            const RtMaterialDev &m = S.mats[in.a];
+            for (int i = 0; i < c; i++) {
+                HitRec &h = A.h[s + i];
+                if (S.mats[h.mat].density > 0.0) {
+                    h.mat = (uint16_t)in.a;
+                    if (m.tex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)m.tex;
+                }
+            }
+            A.l_tag[li] = in.tag;
+            break;
+        }
+        case OP_SURFACE: {                                      /* Surface::Intersect, Solids.cpp:1498-1519 */
+            if (!top_is(A, 2 * in.b)) break;
+            int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
+            const RtSurfaceDev &sf = S.surfs[in.a];
+            for (int i = 0; i < c; i++) {
+                HitRec &h = A.h[s + i];
+                if (h.t == 0.0) continue;
+                h.surf = (uint16_t)in.a;
+                if (sf.tex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)sf.tex;
+            }
+            A.l_tag[li] = in.tag;
+            break;
+        }
+        case OP_UNION: {                                        /* Union::Intersect, Solids.cpp:1060-1075 */
+            bool r = top_is(A, 2 * in.b + 1);
+            bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
+            if (l && r) merge_top(A, MERGE_MAX, S.mats, in.tag);
+            else if (l || r) A.l_tag[A.nlist - 1] = in.tag;
+            break;
+        }
+        case OP_INTER: {                                        /* Intersection::Intersect, Solids.cpp:1139-1158 */
+            bool r = top_is(A, 2 * in.b + 1);
+            bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
+            if (l && r) merge_top(A, MERGE_MIN, S.mats, in.tag);
+            else if (l || r) drop_top(A);
+            break;
+        }
+        case OP_DIFF: {                                         /* Difference::Intersect, Solids.cpp:1177-1196 */
+            bool r = top_is(A, 2 * in.b + 1);
+            bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
+            if (l && r) merge_top(A, MERGE_DIFF, S.mats, in.tag);
+            else if (l) A.l_tag[A.nlist - 1] = in.tag;
+            else if (r) drop_top(A);
+            break;
+        }
+        case OP_SKIP_EMPTY:
+            if (!top_is(A, 2 * in.a)) pc = in.b;
+            break;
+        case OP_ANGCLIP: {                                      /* AngularClip::Intersect, Solids.cpp:1224-1241 */
+            if (!top_is(A, 2 * in.b)) break;
+            const RtClip &c = S.clips[in.a];
+            Work w;
+            work_init(w);
+            clip_plane(rs[depth], d3(c.cv1[0], c.cv1[1], c.cv1[2]), w, 0, 0.0);
+            clip_plane(rs[depth], d3(c.cv2[0], c.cv2[1], c.cv2[2]), w, 1, 0.0);
+            int before = A.nlist;
+            hit_list(w, A, 2 * in.b + 1, 0xFFFF, c.leaf_affine);
+            if (A.nlist > before) merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
+            else {
+                /* Merge(body, empty): every body hit is still filtered through op(pmLeft, vacuum) */
+                if (A.top + 1 <= RT_ARENA && A.nlist < RT_LIST_STACK) {
+                    A.l_start[A.nlist] = (uint16_t)A.top; A.l_count[A.nlist] = 0; A.l_tag[A.nlist] = 2 * in.b + 1; A.nlist++;
+                    merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
+                } else A.overflow = 1;
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+done:
+    if (A.nlist > 0 && A.l_tag[A.nlist - 1] == 0) { start = A.l_start[A.nlist - 1]; return A.l_count[A.nlist - 1]; }
+    start = 0;
+    return 0;
+}
+
+/* ================================================================== lattice noise (Texture.cpp:11-191) */
+RT_DEV uint32_t lattice(uint32_t n)
+{
+    n = 1099087573u * n;
+    uint32_t s = n & 31u;
+    return s ? ((n >> s) | (n << (32u - s))) : n;
+}
+struct F4 { float x, y, z, w; };
+RT_DEV float dot4(const F4 &a, const F4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+#define RT_HALF32 (0.5f * 4294967296.0f)
+
+struct NoiseSetup { F4 coef[4], grad[4]; uint32_t flr[4]; float gain; };
+RT_DEV void noise_setup(NoiseSetup &s, const float *p, int ndim)
+{
+    s.gain = 1.0f;
+    for (int i = 0; i < ndim; i++) {
+        s.gain *= 1.27f;
+        int d = ndim - i;
+        int fl = (int)p[i] - ((p[i] < 0.0f && p[i] != (float)(int)p[i]) ? 1 : 0);
+        float x = p[i] - (float)fl;
+        s.flr[d] = (uint32_t)fl;
+        s.coef[d].x = 1.0f / 6.0f + x * (x * (0.5f - 1.0f / 6.0f * x) - 0.5f);
+        s.coef[d].y = 4.0f / 6.0f + x * x * (0.5f * x - 1.0f);
+        s.coef[d].z = 1.0f / 6.0f + 0.5f * x * (1.0f + x * (1.0f - x));
+        s.coef[d].w = 1.0f / 6.0f * x * x * x;
+        s.grad[d].x = -0.5f + x * (1.0f - 0.5f * x);
+        s.grad[d].y = x * (1.5f * x - 2.0f);
+        s.grad[d].z = 0.5f + x * (1.0f - 1.5f * x);
+        s.grad[d].w = 0.5f * x * x;
+    }
+}
+RT_DEV F4 knots4(uint32_t f, uint32_t lat, uint32_t *h)
+{
+    h[0] = lattice((f - 1) ^ lat); h[1] = lattice(f ^ lat); h[2] = lattice((f + 1) ^ lat); h[3] = lattice((f + 2) ^ lat);
+    F4 k;
+    k.x = (float)h[0] - RT_HALF32; k.y = (float)h[1] - RT_HALF32; k.z = (float)h[2] - RT_HALF32; k.w = (float)h[3] - RT_HALF32;
+    return k;
+}
+/* GradientSpline at dimension 1 / 2 / 3 (Texture.cpp:127-157), recursion unrolled.
+   g1(lat): value, d/dx1.  g2: value, d/dx2 (own), d/dx1.  g3: value, d/dx3, d/dx2, d/dx1 -> stored as grad[0..2]
+   in the reference's order: rgfGradient[0] = own dimension, [1] = next lower, ... */
+RT_DEV float gspline1(const NoiseSetup &s, uint32_t lat, float *g0)
+{
+    uint32_t h[4];
+    F4 k = knots4(s.flr[1], lat, h);
+    *g0 = dot4(s.grad[1], k);
+    return dot4(s.coef[1], k);
+}
+RT_DEV float gspline2(const NoiseSetup &s, uint32_t lat, float *g0, float *g1)
+{
+    uint32_t f = s.flr[2];
+    uint32_t h0 = lattice((f - 1) ^ lat), h1 = lattice(f ^ lat), h2 = lattice((f + 1) ^ lat), h3 = lattice((f + 2) ^ lat);
+    F4 k, gk;
+    k.x = gspline1(s, h0, &gk.x); k.y = gspline1(s, h1, &gk.y); k.z = gspline1(s, h2, &gk.z); k.w = gspline1(s, h3, &gk.w);
+    *g1 = dot4(s.coef[2], gk);
+    *g0 = dot4(s.grad[2], k);
+    return dot4(s.coef[2], k);
+}
+RT_DEV float gspline3(const NoiseSetup &s, uint32_t lat, float *g0, float *g1, float *g2)
+{
+    uint32_t f = s.flr[3];
+    uint32_t h0 = lattice((f - 1) ^ lat), h1 = lattice(f ^ lat), h2 = lattice((f + 1) ^ lat), h3 = lattice((f + 2) ^ lat);
+    F4 k, ga, gb;
+    k.x = gspline2(s, h0, &ga.x, &gb.x); k.y = gspline2(s, h1, &ga.y, &gb.y); k.z = gspline2(s, h2, &ga.z, &gb.z); k.w = gspline2(s, h3, &ga.w, &gb.w);
+    *g1 = dot4(s.coef[3], ga);
+    *g2 = dot4(s.coef[3], gb);
+    *g0 = dot4(s.grad[3], k);
+    return dot4(s.coef[3], k);
+}
+/* GradientBandNoise (Texture.cpp:159-191), nPow == 1, ndim 2 or 3 */
+__device__ float gradient_band_noise(float *g, const float *p, int ndim)
+{
+    NoiseSetup s;
+    noise_setup(s, p, ndim);
+    float v;
+    if (ndim == 3) v = gspline3(s, 123456789u, &g[0], &g[1], &g[2]);
+    else { v = gspline2(s, 123456789u, &g[0], &g[1]); g[2] = 0.0f; }
+    v = s.gain * v * (0.9f / 4294967296.0f) + 0.5f;
+    for (int i = 0; i < ndim; i++) g[i] *= s.gain * (0.9f / 4294967296.0f);
+    return v;
+}
+
+/* ================================================================== shading helpers (Shade.cpp) */
+struct ShadeHit {           /* a hit as the shader sees it after TransformNormals */
+    double t;
+    D3 n, np;
+    int perturbed;
+    int surf, mat;
+};
+
+RT_DEV void perturb(ShadeHit &h, const D3 &d)      /* PerturbNormal, TextureMaps.cpp:189-198 */
+{
+    if (h.perturbed) h.np = h.np + d;
+    else { h.np = normalize(h.n) + d; h.perturbed++; }
+}
+
+__device__ const double kDodeca[20][3] = {
+#define T_  (1.0 / RT_SQRT3)
+#define P1_ (1.61803398874989484820458683436563811772030917980576 / RT_SQRT3)
+#define P2_ ((1.61803398874989484820458683436563811772030917980576 - 1.0) / RT_SQRT3)
+    { T_, T_, T_ }, { T_, T_, -T_ }, { T_, -T_, T_ }, { T_, -T_, -T_ }, { -T_, T_, T_ }, { -T_, T_, -T_ }, { -T_, -T_, T_ }, { -T_, -T_, -T_ },
+    { 0.0, P2_, P1_ }, { 0.0, P2_, -P1_ }, { 0.0, -P2_, P1_ }, { 0.0, -P2_, -P1_ },
+    { P1_, 0.0, P2_ }, { P1_, 0.0, -P2_ }, { -P1_, 0.0, P2_ }, { -P1_, 0.0, -P2_ },
+    { P2_, P1_, 0.0 }, { P2_, -P1_, 0.0 }, { -P2_, P1_, 0.0 }, { -P2_, -P1_, 0.0 }
+#undef T_
+#undef P1_
+#undef P2_
+};
+
+__device__ void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux)        /* TextureMaps.cpp:209-369 */
+{
+    float q[3], g[3];
+    switch (tex) {
+    case RT_TEX_BUMPY: case RT_TEX_MICROFACETS: case RT_TEX_MICROFACETS2: {
+        double sc = tex == RT_TEX_BUMPY ? 50.0 : (tex == RT_TEX_MICROFACETS ? 500.0 : 5000.0);
+        q[0] = (float)(p.x * sc); q[1] = (float)(p.y * sc); q[2] = (float)(p.z * sc);
+        gradient_band_noise(g, q, 3);
+        perturb(h, d3(g[0], g[1], g[2]) * 0.3);
+        return;
+    }
+    case RT_TEX_FIBERS:
+        q[0] = (float)(p.x * 250.0); q[1] = (float)(p.y * 250.0); q[2] = 0.0f;
+        gradient_band_noise(g, q, 2);
+        perturb(h, d3(g[0], g[1], 0.0) * 0.3);
+        return;
+    case RT_TEX_BLISTERED: {
+        q[0] = (float)(p.x * 25.0); q[1] = (float)(p.y * 25.0); q[2] = (float)(p.z * 25.0);
+        float f = gradient_band_noise(g, q, 3);
+        if (f > 0.5) f = -0.5f; else f = 0.0f;
+        perturb(h, d3(g[0], g[1], g[2]) * (double)f);
+        return;
+    }
+    case RT_TEX_FACETED20: {
+        q[0] = (float)(p.x * 50.0); q[1] = (float)(p.y * 50.0); q[2] = (float)(p.z * 50.0);
+        gradient_band_noise(g, q, 3);
+        D3 cv = d3(g[0], g[1], g[2]), best = d3(0, 0, 0);
+        double bestd = -1000000.0;
+        for (int i = 0; i < 20; i++) {
+            D3 c = d3(kDodeca[i][0], kDodeca[i][1], kDodeca[i][2]);
+            double dd = dot(cv, c);
+            if (dd > bestd) { bestd = dd; best = c; }
+        }
+        perturb(h, best * 0.15);
+        return;
+    }
+    case RT_TEX_WAVY: {
+        double f = 0.3 * cos(p.z / (2.0 * RT_PI));
+        perturb(h, d3(f, f, f));
+        return;
+    }
+    case RT_TEX_QUASIMICROFACET: {
+        D3 n = h.perturbed ? h.np : h.n;
+        D3 cu = normalize(cross(n, d3(0.0, 1.0, 0.0)));
+        D3 cvv = normalize(cross(n, cu));
+        double u = aux[4], v = aux[5];
+        u = u * u * u * u * u;
+        v = v * v * v * v * v;
+        perturb(h, (cu * u + cvv * v) * 0.25);
+        return;
+    }
+    default:
+        return;
+    }
+}
+
+/* the ray in the frame of affine k: apply the enclosing transforms root-first (Solids.cpp:905-906) */
+__device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
+{
+    int chain[RT_MAX_AFFINE_DEPTH], n = 0;
+    for (; k >= 0 && n < RT_MAX_AFFINE_DEPTH; k = S.affines[k].tree_parent) chain[n++] = k;
+    DRay r = wray;
+    for (int i = n - 1; i >= 0; --i) {
+        const RtAffine &a = S.affines[chain[i]];
+        DRay nr;
+        nr.dir = mat_vec(a.minv, r.dir);
+        nr.org = mat_vec(a.minv, r.org - d3(a.tr[0], a.tr[1], a.tr[2]));
+        r = nr;
+    }
+    return r;
+}
+
+/* TransformNormals, Shade.cpp:264-284 */
+__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux)
+{
+    h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat;
+    int it = 0, nt = hr.ntex;
+    int pa;
+    for (pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) {
+        while (it < nt && S.texnodes[hr.tex[it]].pa == pa) {
+            const RtTexNode &tn = S.texnodes[hr.tex[it]];
+            DRay lr = ray_in_frame(S, wray, tn.tree_affine);
+            apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
+            it++;
+        }
+        h.n = covec_mat(h.n, S.affines[pa].minv);
+        if (h.perturbed) h.np = covec_mat(h.np, S.affines[pa].minv);
+    }
+    while (it < nt && S.texnodes[hr.tex[it]].pa == -1) {
+        const RtTexNode &tn = S.texnodes[hr.tex[it]];
+        DRay lr = ray_in_frame(S, wray, tn.tree_affine);
+        apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
+        it++;
+    }
+}
+
+/* ConsistentSurfaceNormal, Shade.cpp:62-86 */
+RT_DEV void consistent_normal(const DRay &r, const ShadeHit &h, D3 &vE, D3 &cvN, double &fNE)
+{
+    vE = -normalize(r.dir);
+    if (h.perturbed) {
+        cvN = normalize(h.np);
+        fNE = dot(cvN, vE);
+        double fNE2 = dot(h.n, vE);
+        if (fNE * fNE2 < 0.0) {
+            cvN = normalize(h.n);
+            fNE = dot(cvN, vE);
+        }
+    } else {
+        cvN = normalize(h.n);
+        fNE = dot(cvN, vE);
+    }
+    if (fNE < 0.0) { cvN = -cvN; fNE = -fNE; }
+}
+
+/* FresnelLaw_Real, Shade.cpp:90-113 */
+RT_DEV void fresnel_real(double fNE, double n1, double n2, double &F, double &fNT)
+{
+    double eta = n1 / n2;
+    double crit = 1.0 - 1.0 / (eta * eta);
+    if (crit < 0.0) crit = 0.0; else crit = sqrt(crit);
+    if (fNE < crit) {
+        F = 1.0;
+    } else {
+        fNT = sqrt(1.0 - eta * eta * (1.0 - fNE * fNE));
+        if (n1 == n2) F = 0.0;
+        else {
+            double Rs = (n1 * fNE - n2 * fNT) / (n1 * fNE + n2 * fNT);
+            double Rp = (n1 * fNT - n2 * fNE) / (n1 * fNT + n2 * fNE);
+            F = 0.5 * (Rs * Rs + Rp * Rp);
+        }
+    }
+}
+
+struct Cx { double re, im; };
+RT_DEV Cx cx(double a, double b) { Cx c; c.re = a; c.im = b; return c; }
+RT_DEV Cx cadd(Cx a, Cx b) { return cx(a.re + b.re, a.im + b.im); }
+RT_DEV Cx csub(Cx a, Cx b) { return cx(a.re - b.re, a.im - b.im); }
+RT_DEV Cx cscale(Cx a, double f) { return cx(a.re * f, a.im * f); }
+RT_DEV double cabs2(Cx a) { return a.re * a.re + a.im * a.im; }
+RT_DEV Cx cdiv(Cx a, Cx c)          /* Complex.h:21-33 */
+{
+    double den, q;
+    if (fabs(c.re) < fabs(c.im)) {
+        q = c.re / c.im;
+        den = c.re * q + c.im;
+        return cx((a.re * q + a.im) / den, (a.im * q - a.re) / den);
+    }
+    q = c.im / c.re;
+    den = c.im * q + c.re;
+    return cx((a.im * q + a.re) / den, (a.im - a.re * q) / den);
+}
+/* FresnelLaw_Complex + Fresnel_Spectral, Shade.cpp:117-153 */
+__device__ Spec fresnel_spectral(double fNE, double n1r, const float *nn, const float *kk)
+{
+    Spec s;
+    double F = 0.0;
+    for (int i = 0; i < RT_NSPEC; i++) {
+        Cx n1 = cx(n1r, 0.0), n2 = cx((double)nn[i], (double)kk[i]);
+        Cx eta = cdiv(n1, n2);
+        double crit = 1.0 - 1.0 / cabs2(eta);
+        if (crit < 0.0) crit = 0.0; else crit = sqrt(crit);
+        if (fNE < crit) {
+            F = 1.0;
+        } else {
+            double fNT = sqrt(1.0 - cabs2(eta) * (1.0 - fNE * fNE));
+            Cx Rs = cdiv(csub(cscale(n1, fNE), cscale(n2, fNT)), cadd(cscale(n1, fNE), cscale(n2, fNT)));
+            Cx Rp = cdiv(csub(cscale(n1, fNT), cscale(n2, fNE)), cadd(cscale(n1, fNT), cscale(n2, fNE)));
+            F = 0.5 * (cabs2(Rs) + cabs2(Rp));
+            if (n1.re == n2.re && n1.im == n2.im) F = 0.0;
+        }
+        s.v[i] = (float)F;
+    }
+    return s;
+}
+
+RT_DEV bool spectral_metal(int luster) { return luster >= RT_MAT_COPPER && luster <= RT_MAT_TITANIUM; }
+
+/* BidirectionalReflectance, Shade.cpp:155-234.  hn = the hit's unperturbed normal (SURF_WET) */
+__device__ Spec brdf(int rough, int luster, const Spec &color, const D3 &hn, const D3 &vL, const D3 &vE, const D3 &cvN, double F)
+{
+    const Spec white = spec_const(1.0f);
+    double lambert = 1.0 / RT_PI, kS = 1.0, fBRDF;
+    int logk = 0;
+    D3 nspec = cvN;
+    switch (rough) {
+    case RT_SURF_MATTE:     return color * lambert;
+    case RT_SURF_BURNISHED: logk = 3; break;
+    case RT_SURF_SMOOTH:    logk = 5; kS = 1.0; break;
+    case RT_SURF_WET:       nspec = normalize(hn);     /* falls through */
+    case RT_SURF_SHINY:     logk = 7; kS = 0.60; break;
+    case RT_SURF_POLISHED:  logk = 9; kS = 0.35; break;
+    default: break;
+    }
+    if (logk) {
+        double fNL = dot(cvN, vL), fNLs = dot(nspec, vL), fNE = dot(nspec, vE);
+        D3 vH = normalize(vE + vL);
+        double fNH = dot(nspec, vH);
+        int kappa = 1;
+        double blinn = fNH;
+        while (logk > 0) { blinn = blinn * blinn; kappa = kappa + kappa; logk--; }
+        blinn = kS * ((double)kappa + 2.0) * blinn / (2.0 * RT_PI);
+        double fEH = dot(vE, vH);
+        double f1 = fabs(2.0 * fNH * fNE / fEH), f2 = fabs(2.0 * fNH * fNLs / fEH);
+        double geo = f1 < f2 ? f1 : f2;
+        geo = 1.0 < geo ? 1.0 : geo;
+        fBRDF = blinn * geo / (4.0 * fNL * fNE);
+    } else
+        fBRDF = 0.0;
+    switch (luster) {
+    case RT_MAT_PLASTIC:     return color * lambert + white * (F * fBRDF);
+    case RT_MAT_METAL:       return color * ((1.0 - F) * fBRDF) + white * (F * fBRDF);
+    case RT_MAT_TRANSPARENT: return white * (F * fBRDF);
+    default:
+        if (spectral_metal(luster)) return color * fBRDF;
+    }
+    return spec_const(0.0f);
+}
+
+/* RayReflectance, Shade.cpp:236-256 */
+RT_DEV Spec ray_reflectance(int luster, const Spec &color, double F)
+{
+    const Spec white = spec_const(1.0f);
+    switch (luster) {
+    case RT_MAT_PLASTIC:     return white * F;
+    case RT_MAT_METAL:       return color * (1.0 - F) + white * F;
+    case RT_MAT_TRANSPARENT: return white * F;
+    default:
+        if (spectral_metal(luster)) return color;
+    }
+    return spec_const(0.0f);
+}
+
+/* ColoredGlass / Foggy, TextureMaps.cpp:13-57 */
+__device__ void propagate(int id, const D3 &p0, const D3 &p1, const float *color, Spec &tr, Spec &ster)
+{
+    if (id == RT_PROP_FOGGY) {
+        double t = norm(p1 - p0);
+        for (int i = 0; i < RT_NSPEC; i++) {
+            double sc = (double)color[i] * t, T;
+            if (sc > 87.0) T = 0.0; else T = exp(-sc);
+            tr.v[i] = (float)T;
+            ster.v[i] = (float)((1.0 - T) * 0.1);
+        }
+        return;
+    }
+    ster = spec_const(0.0f);
+    double t = norm(p1 - p0) * 100.0;
+    for (int i = 0; i < RT_NSPEC; i++) {
+        double mu = (double)color[i] * t, T;
+        if (mu > 87.0) T = 0.0; else T = exp(-mu);
+        tr.v[i] = (float)T;
+    }
+}
+
+/* ReflectionDirection / RefractionDirection, Shade.cpp:361-391 */
+RT_DEV D3 reflect_dir(const D3 &cvN, const D3 &vE, const D3 &hn, int perturbed, double fNE)
+{
+    D3 vR = cvN * 2.0 * fNE - vE;
+    if (perturbed && dot(hn, vR) < RT_EPSILON) {
+        D3 n2 = normalize(hn);
+        double fNE2 = dot(n2, vE);
+        vR = n2 * 2.0 * fNE2 - vE;
+    }
+    return vR;
+}
+RT_DEV D3 refract_dir(const D3 &cvN, const D3 &vE, const D3 &hn, int perturbed, double eta, double fNE, double fNT)
+{
+    D3 vT = cvN * (eta * fNE - fNT) - vE * eta;
+    if (perturbed && dot(hn, vT) < RT_EPSILON) {
+        D3 n2 = normalize(hn);
+        double fNE2 = dot(n2, vE);
+        vT = n2 * (eta * fNE2 - fNT) - vE * eta;
+    }
+    return vT;
+}
+
+/* Camera::Emit, Cameras.h:8-67 */
+__device__ DRay camera_emit(const RtCamera &c, double vx, double vy, double uC, double vC)
+{
+    DRay r;
+    D3 org = d3(c.org[0], c.org[1], c.org[2]);
+    double x, y, d;
+    if (c.type == RT_CAM_PERSPECTIVE) {
+        r.org = org;
+        r.dir = d3((vx - 0.5) * 35.0 / c.focal, (vy - 0.5) * 35.0 / c.focal, -1.0);
+        return r;
+    }
+    x = (vx - 0.5) * 35.0 / c.focal;
+    y = (vy - 0.5) * 35.0 / c.focal;
+    if (c.type == RT_CAM_ORTHOGRAPHIC) {
+        r.org = d3(x, y, org.z);
+        r.dir = d3(0.0, 0.0, -1.0);
+        return r;
+    }
+    d = x * x + y * y + 4.0;
+    r.org = org;
+    r.dir = d3(4.0 * x / d, 4.0 * y / d, 1.0 - 8.0 / d);
+    if (c.type == RT_CAM_APERTURE) {
+        DRay r2;
+        r.dir = normalize(r.dir);
+        D3 vX = d3(c.vX[0], c.vX[1], c.vX[2]), vY = d3(c.vY[0], c.vY[1], c.vY[2]);
+        r2.org = r.org + vX * uC + vY * vC;
+        r2.dir = ray_at(r, c.focus_distance) - r2.org;
+        return r2;
+    }
+    return r;
+}

@@ -1,0 +1,130 @@
+/*
+ * rt_device.h -- flattened scene layout shared by the host flattener (rt_flatten.cpp) and the HIP
+ * kernels (rt_kernels.hip).
+ *
+ * The reference walks a pointer tree of virtual Solid::Intersect calls per ray
+ * (RayTracer2020.h:68-75).  Here the optimised tree becomes
+ *   - a linear PROGRAM (post-order, 16-byte instructions) that a per-ray stack machine interprets;
+ *     every list-producing instruction names the instruction that will consume its result, so empty
+ *     lists are never materialised and the pending stack holds non-empty lists only;
+ *   - conservative world-space boxes in front of every finite subtree (skip = BVH-style culling
+ *     that cannot change a hit list: a ray that misses the box yields the empty list either way);
+ *   - SoA parameter tables (affine transforms, primitives, planes, materials, surfaces, texture
+ *     call-outs, lights).
+ * Everything is tiny next to HBM (S0: 257 spheres = ~60 KB) and lives in L2/LDS; the HBM-resident
+ * data of a render are the per-sample and per-frame arrays allocated in rt_api.hip.
+ */
+#pragma once
+#include <stdint.h>
+#include "../../include/rt_scene_desc.h"
+
+#define RT_MAX_AFFINE_DEPTH 12      /* nested (merged) affine levels on a root-to-leaf path */
+#define RT_MAX_TEX          4       /* textured Material/Surface ancestors per hit */
+#define RT_LIST_STACK       24      /* pending non-empty hit lists per ray */
+#define RT_ARENA            64      /* working hits per ray (private memory) */
+#define RT_MAX_LIGHTS       8
+#define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
+
+enum RtOp {
+    OP_END = 0,
+    OP_BOUND,       /* a: box index, b: jump target if the world ray misses the box */
+    OP_REFBOX,      /* a: box index (reference BoundingBox extent, local frame), b: jump target; Solids.h:495 */
+    OP_PUSH_AFFINE, /* a: affine index */
+    OP_POP_AFFINE,
+    OP_QUADRIC,     /* a: primitive index */
+    OP_POLY,        /* a: primitive index */
+    OP_SLAB,        /* a: primitive index */
+    OP_TORUS,       /* a: primitive index */
+    OP_MATERIAL,    /* a: material index (>= 2) */
+    OP_SURFACE,     /* a: surface index (>= 2) */
+    OP_UNION,
+    OP_INTER,
+    OP_DIFF,
+    OP_ANGCLIP,     /* a: clip index */
+    OP_SKIP_EMPTY,  /* b: jump target when the left operand of the binary op at `cons` is empty (Solids.cpp:1152-1157, :1190-1195) */
+    OP_RETAG        /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
+};
+
+/* Every instruction that leaves a list names its consumer: tag = 2 * (consumer pc) + side (0 left / only, 1 right). */
+typedef struct RtInstr {
+    int32_t op;
+    int32_t a;
+    int32_t b;
+    int32_t tag;
+} RtInstr;
+
+typedef struct RtBox { double lo[3], hi[3]; } RtBox;
+
+typedef struct RtAffine {       /* AffineSolid after Optimize() (Solids.cpp:957-983) */
+    double minv[9];             /* mInverse, row major */
+    double tr[3];               /* vTranslate */
+    int32_t link;               /* paParent (normal-transform chain, Shade.cpp:271-279), -1 none */
+    int32_t tree_parent;        /* enclosing affine in the tree (ray-transform chain), -1 none */
+} RtAffine;
+
+typedef struct RtPrim {
+    double  p[4];               /* quadric: P,Q,R ; torus: minor radius */
+    int32_t i0;                 /* quadric: nClip ; polyhedron: nSides */
+    int32_t plane0;             /* polyhedron: first plane (index into planes, 3 doubles each) */
+    int32_t leaf_affine;        /* affine that hits of this primitive record (s_paLastHitAffine, Solids.cpp:213), -1 none */
+    int32_t id;                 /* RtNode.id */
+} RtPrim;
+
+typedef struct RtMaterialDev {  /* index 0 = g_mVacuum, 1 = g_mNeutronium (Solids.cpp:1463-1464) */
+    double  density, refr;
+    float   color[RT_NSPEC];
+    int32_t luster, prop;
+    int32_t tex;                /* texture call-out index (into RtTexNode), -1 none */
+    int32_t id;
+} RtMaterialDev;
+
+typedef struct RtSurfaceDev {   /* index 0 = none (ps == 0), 1 = the static matte surface (Solids.cpp:169) */
+    int32_t roughness;
+    int32_t tex;
+    int32_t id;
+    int32_t pad_;
+} RtSurfaceDev;
+
+typedef struct RtTexNode {      /* a queued TextureMap call-out (Solids.cpp:1476-1483, :1509-1516) */
+    int32_t tex;                /* RtTextureId */
+    int32_t pa;                 /* paAffineTransforms of the owning node: level at which it fires, -1 = none */
+    int32_t tree_affine;        /* innermost affine enclosing the owning node in the tree: frame of pt->p = ray(t) */
+    int32_t pad_;
+} RtTexNode;
+
+typedef struct RtClip {         /* AngularClip, Solids.h:409-419 */
+    double  cv1[3], cv2[3];
+    int32_t intersect;
+    int32_t leaf_affine;
+    int32_t id;
+    int32_t pad_;
+} RtClip;
+
+typedef struct RtLightDev {
+    double  org[3], vA[3], vB[3];
+    float   flux[RT_NSPEC];
+    int32_t type, no_shadow;
+} RtLightDev;
+
+/* constant part of a scene, one copy in device memory */
+typedef struct RtDevScene {
+    const RtInstr       *prog;
+    const RtBox         *boxes;
+    const RtAffine      *affines;
+    const RtPrim        *prims;
+    const double        *planes;
+    const RtMaterialDev *mats;
+    const RtSurfaceDev  *surfs;
+    const RtTexNode     *texnodes;
+    const RtClip        *clips;
+    const RtLightDev    *lights;
+    const double        *blue;          /* g_rgvBlueNoise: 1600 x 2 */
+    const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
+    const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
+    int32_t n_prog, n_lights, has_ambient, sampler, venera, pad_;
+    float   ambient[RT_NSPEC];
+    float   spec2rgb[RT_NSPEC][3];
+    float   chan[3][RT_NSPEC];
+    RtCamera cam;
+    double  aux_init[6];
+} RtDevScene;

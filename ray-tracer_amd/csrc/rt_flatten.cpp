@@ -1,0 +1,394 @@
+/*
+ * rt_flatten.cpp -- turn the optimised object graph (RtSceneDesc) into the per-ray program and the
+ * SoA tables the kernels read (rt_device.h).  Host only; runs once per scene upload.
+ *
+ * Culling boxes are this build's own CONSERVATIVE bounds, not the reference's GetExtent() (which
+ * returns the unit cube for every quadric and polyhedron, Solids.h:69, Solids.cpp:789): a box may
+ * only be used to skip a subtree if missing it implies the reference's hit list is empty.  The
+ * reference's own BoundingBox nodes keep their (possibly too small) extents and their semantics
+ * (OP_REFBOX), because dropping hits outside them is visible in the reference's images.
+ */
+#include <math.h>
+#include <string.h>
+#include <stdio.h>
+#include "rt_flatten.h"
+#include "../../include/rt_amd.h"
+
+namespace {
+
+const double kHuge = 1.0e300;
+
+struct Box {
+    double lo[3], hi[3];
+    bool empty;
+    Box() : empty(true) { for (int i = 0; i < 3; i++) { lo[i] = kHuge; hi[i] = -kHuge; } }
+    static Box infinite() { Box b; b.empty = false; for (int i = 0; i < 3; i++) { b.lo[i] = -kHuge; b.hi[i] = kHuge; } return b; }
+    static Box cube(double lx, double ly, double lz, double hx, double hy, double hz)
+    { Box b; b.empty = false; b.lo[0] = lx; b.lo[1] = ly; b.lo[2] = lz; b.hi[0] = hx; b.hi[1] = hy; b.hi[2] = hz; return b; }
+    bool finite() const { if (empty) return true; for (int i = 0; i < 3; i++) if (lo[i] < -1e200 || hi[i] > 1e200) return false; return true; }
+};
+
+Box box_union(const Box &a, const Box &b)
+{
+    if (a.empty) return b;
+    if (b.empty) return a;
+    Box r; r.empty = false;
+    for (int i = 0; i < 3; i++) { r.lo[i] = fmin(a.lo[i], b.lo[i]); r.hi[i] = fmax(a.hi[i], b.hi[i]); }
+    return r;
+}
+Box box_intersect(const Box &a, const Box &b)
+{
+    if (a.empty || b.empty) return Box();
+    Box r; r.empty = false;
+    for (int i = 0; i < 3; i++) { r.lo[i] = fmax(a.lo[i], b.lo[i]); r.hi[i] = fmin(a.hi[i], b.hi[i]); if (r.lo[i] > r.hi[i]) return Box(); }
+    return r;
+}
+/* image of a box under p -> M p + T (forward transform = inverse of minv); any infinite side makes it infinite */
+Box box_transform(const Box &b, const double *m, const double *t)
+{
+    if (b.empty) return b;
+    if (!b.finite()) return Box::infinite();
+    Box r; r.empty = false;
+    for (int i = 0; i < 3; i++) { r.lo[i] = kHuge; r.hi[i] = -kHuge; }
+    for (int c = 0; c < 8; c++) {
+        double p[3] = { (c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2] };
+        for (int i = 0; i < 3; i++) {
+            double q = m[3 * i] * p[0] + m[3 * i + 1] * p[1] + m[3 * i + 2] * p[2] + t[i];
+            r.lo[i] = fmin(r.lo[i], q); r.hi[i] = fmax(r.hi[i], q);
+        }
+    }
+    return r;
+}
+
+/* solid { x^2 + y^2 + P z^2 + Q z + R <= 0 }, optionally capped to |z| <= 1 */
+Box quadric_bound(double P, double Q, double R, int clip)
+{
+    if (clip == -1) return Box::infinite();
+    double z0, z1;
+    if (clip == 1) { z0 = -1.0; z1 = 1.0; }
+    else {
+        if (!(P > 0.0)) return Box::infinite();
+        double disc = Q * Q - 4.0 * P * R;
+        if (disc < 0.0) return Box();       /* no real points */
+        double s = sqrt(disc);
+        z0 = (-Q - s) / (2.0 * P); z1 = (-Q + s) / (2.0 * P);
+    }
+    /* r^2(z) = -(P z^2 + Q z + R), maximised over [z0,z1] */
+    double zs[3] = { z0, z1, z0 }; int n = 2;
+    if (P != 0.0) { double zv = -Q / (2.0 * P); if (zv > z0 && zv < z1) { zs[2] = zv; n = 3; } }
+    double r2 = 0.0;
+    for (int i = 0; i < n; i++) r2 = fmax(r2, -(P * zs[i] * zs[i] + Q * zs[i] + R));
+    if (!(r2 < 1e200)) return Box::infinite();
+    double r = sqrt(r2);
+    return Box::cube(-r, -r, z0, r, r, z1);
+}
+
+/* convex polyhedron { n_i . p <= 1 } */
+Box polyhedron_bound(const double *pl, int n)
+{
+    if (n < 4) return Box::infinite();
+    /* bounded iff every direction has a plane facing it; tested on a dense direction set */
+    const int ND = 4000;
+    for (int k = 0; k < ND; k++) {
+        double z = 1.0 - 2.0 * (k + 0.5) / ND, r = sqrt(fmax(0.0, 1.0 - z * z)), a = k * 2.399963229728653;
+        double d[3] = { r * cos(a), r * sin(a), z };
+        double best = -1.0;
+        for (int i = 0; i < n; i++) best = fmax(best, pl[3 * i] * d[0] + pl[3 * i + 1] * d[1] + pl[3 * i + 2] * d[2]);
+        if (best < 1e-6) return Box::infinite();
+    }
+    Box b;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            for (int k = j + 1; k < n; k++) {
+                const double *a = pl + 3 * i, *bb = pl + 3 * j, *c = pl + 3 * k;
+                double det = a[0] * (bb[1] * c[2] - bb[2] * c[1]) - a[1] * (bb[0] * c[2] - bb[2] * c[0]) + a[2] * (bb[0] * c[1] - bb[1] * c[0]);
+                if (fabs(det) < 1e-12) continue;
+                /* a.p = b.p = c.p = 1  =>  p = (b x c + c x a + a x b) / det */
+                double x = ((bb[1] * c[2] - bb[2] * c[1]) + (c[1] * a[2] - c[2] * a[1]) + (a[1] * bb[2] - a[2] * bb[1])) / det;
+                double y = ((bb[2] * c[0] - bb[0] * c[2]) + (c[2] * a[0] - c[0] * a[2]) + (a[2] * bb[0] - a[0] * bb[2])) / det;
+                double z = ((bb[0] * c[1] - bb[1] * c[0]) + (c[0] * a[1] - c[1] * a[0]) + (a[0] * bb[1] - a[1] * bb[0])) / det;
+                bool in = true;
+                for (int q = 0; q < n && in; q++) if (pl[3 * q] * x + pl[3 * q + 1] * y + pl[3 * q + 2] * z > 1.0 + 1e-7) in = false;
+                if (!in) continue;
+                Box p = Box::cube(x, y, z, x, y, z);
+                b = box_union(b, p);
+            }
+    if (b.empty) return Box::infinite();    /* should not happen for a bounded solid: stay conservative */
+    return b;
+}
+
+struct Flattener {
+    const RtSceneDesc *d;
+    RtFlatScene &o;
+    std::string &err;
+    int rc;
+    bool with_bounds;
+    int next_uid;
+    int last_affine;                /* static image of s_paLastHitAffine (Solids.cpp:170) */
+    std::vector<int> node_affine;   /* desc node index -> affine table index (for link resolution) */
+    std::vector<int> affine_stack;  /* enclosing affine table indices */
+    struct Fwd { double m[9], t[3]; };
+    std::vector<Fwd> fwd_stack;     /* forward transforms of enclosing affines (for world boxes) */
+    int tex_depth;
+
+    Flattener(const RtSceneDesc *dd, RtFlatScene &oo, std::string &e, bool wb)
+        : d(dd), o(oo), err(e), rc(0), with_bounds(wb), next_uid(1), last_affine(-1), tex_depth(0) {}
+
+    bool fail(int code, const std::string &m) { if (!rc) { rc = code; err = m; } return false; }
+    const RtNode &N(int i) const { return d->nodes[i]; }
+    const double *D(int i) const { return d->data + d->nodes[i].data; }
+
+    /* conservative bound of node i in ITS OWN frame */
+    Box local_bound(int i)
+    {
+        if (i < 0) return Box();
+        const RtNode &n = N(i);
+        const double *p = D(i);
+        switch (n.type) {
+        case RT_NODE_QUADRIC: case RT_NODE_CONEHYPERCYL: return quadric_bound(p[0], p[1], p[2], n.i0);
+        case RT_NODE_POLYHEDRON: return polyhedron_bound(p, n.i0);
+        case RT_NODE_SLAB: return Box::cube(-kHuge, -kHuge, -1.0, kHuge, kHuge, 1.0);
+        case RT_NODE_TORUS: return Box::cube(-1.0 - p[0], -1.0 - p[0], -p[0], 1.0 + p[0], 1.0 + p[0], p[0]);
+        case RT_NODE_AFFINE: return box_transform(local_bound(n.left), p, p + 18);
+        case RT_NODE_UNION: case RT_NODE_TOPUNION: return box_union(local_bound(n.left), local_bound(n.right));
+        case RT_NODE_INTERSECTION: return box_intersect(local_bound(n.left), local_bound(n.right));
+        case RT_NODE_DIFFERENCE: return local_bound(n.left);
+        case RT_NODE_ANGULARCLIP: case RT_NODE_BOUNDINGBOX: case RT_NODE_MATERIAL: case RT_NODE_SURFACE: return local_bound(n.left);
+        default: return Box();
+        }
+    }
+    Box to_world(Box b)
+    {
+        for (int k = (int)fwd_stack.size() - 1; k >= 0 && !b.empty; --k) b = box_transform(b, fwd_stack[k].m, fwd_stack[k].t);
+        return b;
+    }
+    int add_box(const Box &b, bool pad)
+    {
+        RtBox r;
+        for (int i = 0; i < 3; i++) {
+            double e = pad ? 1e-6 * (fabs(b.hi[i] - b.lo[i]) + fabs(b.lo[i]) + fabs(b.hi[i])) + 1e-9 : 0.0;
+            r.lo[i] = b.lo[i] - e; r.hi[i] = b.hi[i] + e;
+        }
+        o.boxes.push_back(r);
+        return (int)o.boxes.size() - 1;
+    }
+    int push(int op, int a, int b, int tag)
+    {
+        RtInstr in; in.op = op; in.a = a; in.b = b; in.tag = tag;
+        o.prog.push_back(in);
+        return (int)o.prog.size() - 1;
+    }
+    bool can_hit(int i)     /* false when the subtree is statically empty */
+    {
+        if (i < 0) return false;
+        const RtNode &n = N(i);
+        switch (n.type) {
+        case RT_NODE_NULL: return false;
+        case RT_NODE_AFFINE: case RT_NODE_ANGULARCLIP: case RT_NODE_BOUNDINGBOX: case RT_NODE_MATERIAL: case RT_NODE_SURFACE: return can_hit(n.left);
+        case RT_NODE_UNION: case RT_NODE_TOPUNION: return can_hit(n.left) || can_hit(n.right);
+        case RT_NODE_INTERSECTION: return can_hit(n.left) && can_hit(n.right);
+        case RT_NODE_DIFFERENCE: return can_hit(n.left);
+        default: return true;
+        }
+    }
+    int leaf(int type_op, int i)
+    {
+        const RtNode &n = N(i);
+        const double *p = D(i);
+        RtPrim pr;
+        memset(&pr, 0, sizeof pr);
+        pr.id = n.id; pr.leaf_affine = last_affine; pr.i0 = n.i0; pr.plane0 = -1;
+        int enclosing = affine_stack.empty() ? -1 : affine_stack.back();
+        if (last_affine != enclosing) o.irregular_leaves++;
+        if (type_op == OP_QUADRIC) { pr.p[0] = p[0]; pr.p[1] = p[1]; pr.p[2] = p[2]; }
+        else if (type_op == OP_TORUS) pr.p[0] = p[0];
+        else if (type_op == OP_POLY) {
+            pr.plane0 = (int)o.planes.size() / 3;
+            o.planes.insert(o.planes.end(), p, p + 3 * n.i0);
+            if (n.i0 < 1) fail(RT_ERR_INVALID, "polyhedron without planes");
+        }
+        o.prims.push_back(pr);
+        return (int)o.prims.size() - 1;
+    }
+    int tex_node(int tex_id, int link_node)
+    {
+        static const bool ok[RT_TEX__COUNT] = { true, true, true, true, false, true, false, true, true, true, false, false, true };
+        if (tex_id <= 0) return -1;
+        if (tex_id >= RT_TEX__COUNT || !ok[tex_id]) { fail(RT_ERR_UNSUPPORTED, "texture call-out without a device routine yet (id " + std::to_string(tex_id) + ")"); return -1; }
+        RtTexNode t;
+        t.tex = tex_id;
+        t.pa = (link_node >= 0 && link_node < (int)node_affine.size()) ? node_affine[link_node] : -1;
+        t.tree_affine = affine_stack.empty() ? -1 : affine_stack.back();
+        t.pad_ = 0;
+        o.texnodes.push_back(t);
+        return (int)o.texnodes.size() - 1;
+    }
+
+    /* emit code for subtree i whose result goes to `tag`; precondition can_hit(i) */
+    void emit(int i, int tag)
+    {
+        if (rc) return;
+        const RtNode &n = N(i);
+        int bound_pc = -1;
+        bool is_leaf = (n.type >= RT_NODE_QUADRIC && n.type <= RT_NODE_TORUS) || n.type == RT_NODE_CONEHYPERCYL;
+        /* a box in front of: every leaf, every affine, every binary node (not in front of pure wrappers: same box as their child) */
+        bool boxed = with_bounds && (is_leaf || n.type == RT_NODE_AFFINE || (n.type >= RT_NODE_UNION && n.type <= RT_NODE_DIFFERENCE));
+        if (boxed) {
+            Box b = to_world(local_bound(i));
+            if (b.empty) return;                       /* no points at all: statically empty */
+            if (b.finite()) { bound_pc = push(OP_BOUND, add_box(b, true), -1, 0); o.culled_subtrees++; }
+        }
+        switch (n.type) {
+        case RT_NODE_QUADRIC: case RT_NODE_CONEHYPERCYL: push(OP_QUADRIC, leaf(OP_QUADRIC, i), 0, tag); break;
+        case RT_NODE_POLYHEDRON: push(OP_POLY, leaf(OP_POLY, i), 0, tag); break;
+        case RT_NODE_SLAB: push(OP_SLAB, leaf(OP_SLAB, i), 0, tag); break;
+        case RT_NODE_TORUS: push(OP_TORUS, leaf(OP_TORUS, i), 0, tag); break;
+        case RT_NODE_AFFINE: {
+            const double *p = D(i);
+            RtAffine a;
+            memcpy(a.minv, p + 9, sizeof a.minv);
+            memcpy(a.tr, p + 18, sizeof a.tr);
+            a.tree_parent = affine_stack.empty() ? -1 : affine_stack.back();
+            a.link = (n.link >= 0 && n.link < (int)node_affine.size()) ? node_affine[n.link] : -1;
+            int k = (int)o.affines.size();
+            o.affines.push_back(a);
+            node_affine[i] = k;
+            if ((int)affine_stack.size() + 1 > RT_MAX_AFFINE_DEPTH) { fail(RT_ERR_UNSUPPORTED, "affine nesting deeper than RT_MAX_AFFINE_DEPTH"); return; }
+            Fwd f; memcpy(f.m, p, sizeof f.m); memcpy(f.t, p + 18, sizeof f.t);
+            affine_stack.push_back(k); fwd_stack.push_back(f);
+            last_affine = k;
+            push(OP_PUSH_AFFINE, k, 0, 0);
+            emit(n.left, tag);
+            push(OP_POP_AFFINE, 0, 0, 0);
+            affine_stack.pop_back(); fwd_stack.pop_back();
+            break;
+        }
+        case RT_NODE_UNION: case RT_NODE_TOPUNION: {
+            bool l = can_hit(n.left), r = can_hit(n.right);
+            if (l && r) {
+                int uid = next_uid++;
+                emit(n.left, 2 * uid);
+                emit(n.right, 2 * uid + 1);
+                push(OP_UNION, 0, uid, tag);
+            } else emit(l ? n.left : n.right, tag);
+            break;
+        }
+        case RT_NODE_INTERSECTION: {
+            int uid = next_uid++;
+            emit(n.left, 2 * uid);
+            int sk = push(OP_SKIP_EMPTY, uid, -1, 0);
+            emit(n.right, 2 * uid + 1);
+            push(OP_INTER, 0, uid, tag);
+            o.prog[sk].b = (int)o.prog.size();
+            break;
+        }
+        case RT_NODE_DIFFERENCE: {
+            if (!can_hit(n.right)) { emit(n.left, tag); break; }
+            int uid = next_uid++;
+            emit(n.left, 2 * uid);
+            int sk = push(OP_SKIP_EMPTY, uid, -1, 0);
+            emit(n.right, 2 * uid + 1);
+            push(OP_DIFF, 0, uid, tag);
+            o.prog[sk].b = (int)o.prog.size();
+            break;
+        }
+        case RT_NODE_ANGULARCLIP: {
+            const double *p = D(i);
+            int uid = next_uid++;
+            emit(n.left, 2 * uid);
+            RtClip c;
+            memset(&c, 0, sizeof c);
+            memcpy(c.cv1, p, sizeof c.cv1); memcpy(c.cv2, p + 3, sizeof c.cv2);
+            c.intersect = n.i0; c.leaf_affine = last_affine; c.id = n.id;
+            o.clips.push_back(c);
+            push(OP_ANGCLIP, (int)o.clips.size() - 1, uid, tag);
+            break;
+        }
+        case RT_NODE_BOUNDINGBOX: {
+            const double *p = D(i);
+            Box b = Box::cube(p[0], p[1], p[2], p[3], p[4], p[5]);
+            int pc = push(OP_REFBOX, add_box(b, false), -1, 0);
+            emit(n.left, tag);
+            o.prog[pc].b = (int)o.prog.size();
+            break;
+        }
+        case RT_NODE_MATERIAL: {
+            const double *p = D(i);
+            if (n.i0 < RT_MAT_NOSHADE || n.i0 > RT_MAT_TITANIUM) { fail(RT_ERR_INVALID, "material luster out of range"); return; }
+            if (n.i2 < 0 || n.i2 >= RT_PROP__COUNT) { fail(RT_ERR_UNSUPPORTED, "unknown propagator"); return; }
+            RtMaterialDev m;
+            memset(&m, 0, sizeof m);
+            m.density = p[0]; m.refr = p[1];
+            for (int k = 0; k < RT_NSPEC; k++) m.color[k] = (float)p[2 + k];
+            m.luster = n.i0; m.prop = n.i2; m.id = n.id;
+            if (n.i1 && ++tex_depth > RT_MAX_TEX) { fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"); return; }
+            m.tex = tex_node(n.i1, n.link);
+            int mi = (int)o.mats.size();
+            o.mats.push_back(m);
+            int uid = next_uid++;
+            emit(n.left, 2 * uid);
+            push(OP_MATERIAL, mi, uid, tag);
+            if (n.i1) tex_depth--;
+            break;
+        }
+        case RT_NODE_SURFACE: {
+            RtSurfaceDev s;
+            memset(&s, 0, sizeof s);
+            s.roughness = n.i0; s.id = n.id;
+            if (n.i1 && ++tex_depth > RT_MAX_TEX) { fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"); return; }
+            s.tex = tex_node(n.i1, n.link);
+            int si = (int)o.surfs.size();
+            o.surfs.push_back(s);
+            int uid = next_uid++;
+            emit(n.left, 2 * uid);
+            push(OP_SURFACE, si, uid, tag);
+            if (n.i1) tex_depth--;
+            break;
+        }
+        default:
+            fail(RT_ERR_INVALID, "unknown node type " + std::to_string(n.type));
+            return;
+        }
+        if (bound_pc >= 0) o.prog[bound_pc].b = (int)o.prog.size();
+    }
+};
+
+} // namespace
+
+int rt_flatten_scene(const RtSceneDesc *d, RtFlatScene &out, std::string &err, bool with_bounds)
+{
+    if (!d || d->n_nodes < 0 || (d->n_nodes && !d->nodes)) { err = "null scene description"; return RT_ERR_INVALID; }
+    for (int i = 0; i < d->n_nodes; i++) {
+        const RtNode &n = d->nodes[i];
+        if (n.left >= d->n_nodes || n.right >= d->n_nodes || n.link >= d->n_nodes || n.data < 0 || n.data + n.ndata > d->n_data) { err = "node index out of range"; return RT_ERR_INVALID; }
+        if (n.left >= 0 && n.left <= i) { err = "scene is not a tree in pre-order"; return RT_ERR_INVALID; }
+        if (n.right >= 0 && n.right <= i) { err = "scene is not a tree in pre-order"; return RT_ERR_INVALID; }
+    }
+    if (d->n_lights > RT_MAX_LIGHTS) { err = "more than RT_MAX_LIGHTS point lights"; return RT_ERR_UNSUPPORTED; }
+    Flattener f(d, out, err, with_bounds);
+    f.node_affine.assign((size_t)(d->n_nodes > 0 ? d->n_nodes : 1), -1);
+    /* built-in materials / surfaces (Solids.cpp:1463-1464, :169) */
+    RtMaterialDev vac, neu;
+    memset(&vac, 0, sizeof vac); memset(&neu, 0, sizeof neu);
+    vac.density = 0.0; vac.refr = 1.0 + 0.0; vac.luster = RT_MAT_TRANSPARENT; vac.tex = -1; vac.id = -1;
+    neu.density = 1000000.0; neu.refr = 1.0 + 1000000.0; neu.luster = RT_MAT_PLASTIC; neu.tex = -1; neu.id = -2;
+    for (int k = 0; k < RT_NSPEC; k++) { vac.color[k] = 0.0f; neu.color[k] = 1.0f; }
+    out.mats.push_back(vac); out.mats.push_back(neu);
+    RtSurfaceDev none, matte;
+    memset(&none, 0, sizeof none); memset(&matte, 0, sizeof matte);
+    none.roughness = RT_SURF_MATTE; none.tex = -1; none.id = -9;
+    matte.roughness = RT_SURF_MATTE; matte.tex = -1; matte.id = -3;
+    out.surfs.push_back(none); out.surfs.push_back(matte);
+    if (d->root >= 0 && f.can_hit(d->root)) f.emit(d->root, 0);
+    f.push(OP_END, 0, 0, 0);
+    if (f.rc) return f.rc;
+    for (int i = 0; i < d->n_lights; i++) {
+        RtLightDev l;
+        memset(&l, 0, sizeof l);
+        memcpy(l.org, d->lights[i].org, sizeof l.org); memcpy(l.vA, d->lights[i].vA, sizeof l.vA); memcpy(l.vB, d->lights[i].vB, sizeof l.vB);
+        memcpy(l.flux, d->lights[i].flux, sizeof l.flux);
+        l.type = d->lights[i].type; l.no_shadow = d->lights[i].no_shadow;
+        out.lights.push_back(l);
+    }
+    return 0;
+}

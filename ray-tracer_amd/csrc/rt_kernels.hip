@@ -1,0 +1,577 @@
+/*
+ * rt_kernels.hip -- the wavefront pipeline behind RayTracer::Render (RayTracer2020.cpp:33-38) on gfx950.
+ *
+ * The reference evaluates one sample at a time through mutually recursive VisualRay / LightRay calls
+ * (Shade.cpp:301-520).  Here a chunk of samples advances level by level through queues in HBM:
+ *
+ *   k_generate   sample index -> sample position + auxiliary dimensions (Sampling.cpp:335-346, 498-517)
+ *                -> camera ray (Cameras.h) -> root frame
+ *   k_visual     one visual ray per lane: CSG intersection (stack machine, rt_core.hip.h), walk of the hit
+ *                list through transparent media up to the first boundary (Shade.cpp:433-511), ambient
+ *                term; appends one shadow ray per light that can see the surface to the shadow queue
+ *   k_shadow     one shadow ray per lane: intersection + transmission walk (Shade.cpp:301-359)
+ *   k_shade      per frame: sums the lights in the reference's order (Shade.cpp:477-489), then appends
+ *                the reflection / refraction child frames (Shade.cpp:490-501) to the next level's queue
+ *   k_resolve    deepest level first: R = ((R + refl*w1) + refr*w2) * tr (+ sterisent), result handed
+ *                to the parent frame or, at level 0, converted to RGB (RadiometryColor.h:62-66)
+ *
+ * Queue appends are compacted per wavefront: a 64-lane prefix sum over the lanes' counts and ONE atomic
+ * per wave.  All frame / shadow-ray state is SoA ([field][index]) so that consecutive lanes touch
+ * consecutive addresses.
+ */
+#include "rt_core.hip.h"
+#include "rt_pipeline.h"
+
+/* ------------------------------------------------------------------ wave-level queue allocation */
+__device__ int wave_alloc(int count, int *counter)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = count;
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - count;
+}
+
+RT_DEV void spec_store(float *base, size_t cap, size_t idx, const Spec &s) { for (int k = 0; k < RT_NSPEC; k++) base[(size_t)k * cap + idx] = s.v[k]; }
+RT_DEV Spec spec_fetch(const float *base, size_t cap, size_t idx) { Spec s; for (int k = 0; k < RT_NSPEC; k++) s.v[k] = base[(size_t)k * cap + idx]; return s; }
+RT_DEV void d3_store(double *base, size_t cap, int field, size_t idx, const D3 &v) { base[(size_t)field * cap + idx] = v.x; base[(size_t)(field + 1) * cap + idx] = v.y; base[(size_t)(field + 2) * cap + idx] = v.z; }
+RT_DEV D3 d3_fetch(const double *base, size_t cap, int field, size_t idx) { return d3(base[(size_t)field * cap + idx], base[(size_t)(field + 1) * cap + idx], base[(size_t)(field + 2) * cap + idx]); }
+
+/* ------------------------------------------------------------------ sample generation + camera */
+__device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s, double *pos2, double *v2, double *aux)
+{
+    if (g.sampler == RT_SAMPLER_TEST) {                 /* TestSamplingTile::Render, Sampling.cpp:324-348 */
+        int j = g.test_row0 + (int)(s / g.width), i = (int)(s % g.width);
+        int n = g.width, nHi = g.height;
+        v2[1] = ((double)j + (double)((n - nHi) / 2) + 0.5) / (double)n;
+        v2[0] = ((double)i + 0.5) / (double)n;
+        pos2[0] = (double)i + 0.5; pos2[1] = (double)j + 0.5;
+        for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
+        return;
+    }
+    /* FastBlueSamplingTile::Render, Sampling.cpp:498-517: tile x outer, tile y inner, i innermost */
+    int64_t tile = s / RT_BLUE_N;
+    int i = (int)(s % RT_BLUE_N);
+    int tx = (int)(tile / g.tiles_y_local), ty = (int)(tile % g.tiles_y_local) + g.tile_y0;
+    double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
+    double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + vtx, vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + vty;
+    pos2[0] = vx; pos2[1] = vy;
+    v2[0] = (vx + g.adjust_x) / g.size; v2[1] = (vy + g.adjust_y) / g.size;
+    int q3 = S.qi3[i % RT_BLUE_N], q2 = S.qi2[i % RT_BLUE_N];
+    aux[0] = 2.0 * S.blue[2 * q3] - 1.0;
+    aux[1] = 2.0 * S.blue[2 * q3 + 1] - 1.0;
+    aux[2] = 2.0 * S.blue[2 * q2] - 1.0;
+    aux[3] = 2.0 * S.blue[2 * q2 + 1] - 1.0;
+    aux[4] = aux[2];
+    aux[5] = aux[3];
+}
+
+__global__ void k_probe_samples(const RtDevScene *Sp, RtSampleGrid g, int64_t first, int64_t n, double *out8, double *out_xy)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double pos[2], v[2], aux[6];
+    sample_at(*Sp, g, first + k, pos, v, aux);
+    out8[8 * k] = v[0]; out8[8 * k + 1] = v[1];
+    for (int i = 0; i < 6; i++) out8[8 * k + 2 + i] = aux[i];
+    out_xy[2 * k] = pos[0]; out_xy[2 * k + 1] = pos[1];
+}
+
+__global__ void k_probe_camera(const RtDevScene *Sp, int n, const double *v2, const double *aux6, double *org, double *dir)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RtDevScene &S = *Sp;
+    double uC = aux6 ? aux6[6 * k] : S.aux_init[0], vC = aux6 ? aux6[6 * k + 1] : S.aux_init[1];
+    DRay r = camera_emit(S.cam, v2[2 * k], v2[2 * k + 1], uC, vC);
+    org[3 * k] = r.org.x; org[3 * k + 1] = r.org.y; org[3 * k + 2] = r.org.z;
+    dir[3 * k] = r.dir.x; dir[3 * k + 1] = r.dir.y; dir[3 * k + 2] = r.dir.z;
+}
+
+/* root frames for samples [first, first+n) of the grid; or for user rays (probe) when rays != 0 */
+__global__ void __launch_bounds__(256) k_generate(const RtDevScene *Sp, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RtDevScene &S = *Sp;
+    double aux[6];
+    DRay r;
+    if (rays_org) {
+        r.org = d3(rays_org[3 * k], rays_org[3 * k + 1], rays_org[3 * k + 2]);
+        r.dir = d3(rays_dir[3 * k], rays_dir[3 * k + 1], rays_dir[3 * k + 2]);
+        for (int i = 0; i < 6; i++) aux[i] = rays_aux ? rays_aux[6 * k + i] : S.aux_init[i];
+    } else {
+        double pos[2], v[2];
+        sample_at(S, g, first + k, pos, v, aux);
+        r = camera_emit(S.cam, v[0], v[1], aux[0], aux[1]);     /* CastFunction, RayTracer2020.cpp:20-31 */
+    }
+    d3_store(P.f_ray, P.fcap, 0, k, r.org);
+    d3_store(P.f_ray, P.fcap, 3, k, r.dir);
+    for (int i = 0; i < 6; i++) P.aux[(size_t)i * P.ncap + k] = aux[i];
+    P.f_parent[k] = -1;
+    P.f_root[k] = k;
+    P.f_flags[k] = 0;
+}
+
+/* ------------------------------------------------------------------ k_visual */
+__global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, int f0, int f1)
+{
+    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = f < f1;
+    const RtDevScene &S = *Sp;
+    int n_shadow = 0;
+    unsigned mask = 0;
+    DRay sdir[1];
+    (void)sdir;
+    D3 Ppt = d3(0, 0, 0);
+    double aux[6];
+    int flags = 0;
+    if (live) {
+        flags = P.f_flags[f] & FR_KEEP_MASK;
+        DRay ray;
+        ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
+        ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
+        int root = P.f_root[f];
+        for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
+        Arena A;
+        int start;
+        int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+        if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+        atomicAdd(&P.counters[FR_DEPTH(flags) == 0 ? CTR_PRIMARY : CTR_SECONDARY], 1);
+        /* Shade.cpp:424-432: regularise into (0, t, ...) */
+        int i = 0, pm = 0;
+        if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
+        double t = 0.0;
+        Spec tr = spec_const(1.0f), R = spec_const(0.0f);
+        for (; i < count; i++) {
+            ShadeHit h;
+            transform_normals(S, ray, A.h[start + i], h, aux);
+            const RtMaterialDev &mp = S.mats[pm];
+            if (mp.luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
+                R = spec_load(mp.color);
+                flags |= FR_FINAL;
+                break;
+            }
+            if (mp.prop) {
+                Spec ptr, pst;
+                propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+                tr = tr * ptr;
+                R = R + pst;
+            }
+            const RtMaterialDev &mh = S.mats[h.mat];
+            if ((mp.refr != mh.refr) || (mh.luster != RT_MAT_TRANSPARENT)) {
+                D3 vE, cvN;
+                double fNE, F = 0.0, fNT = 0.0;
+                consistent_normal(ray, h, vE, cvN, fNE);
+                Spec color = spec_load(mh.color);
+                if (spectral_metal(mh.luster)) {                /* Q3 */
+                    color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC + RT_NSPEC);
+                    F = 1.0;
+                } else
+                    fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
+                int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
+                if (S.has_ambient && rough != RT_SURF_POLISHED) {
+                    Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
+                    R = R + color * E;
+                }
+                Ppt = ray_at(ray, h.t);
+                /* which lights get a shadow ray (Shade.cpp:477-481) */
+                for (int li = 0; li < S.n_lights; li++) {
+                    const RtLightDev &l = S.lights[li];
+                    D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+                    if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+                    D3 dir = lo - Ppt;
+                    if (dot(cvN, dir) <= 0.0 && mh.luster != RT_MAT_TRANSPARENT) continue;
+                    if (l.no_shadow) continue;
+                    mask |= 1u << li;
+                    n_shadow++;
+                }
+                flags |= FR_BOUNDARY;
+                if (h.perturbed) flags |= FR_PERTURBED;
+                d3_store(P.f_geo, P.fcap, GEO_P, f, Ppt);
+                d3_store(P.f_geo, P.fcap, GEO_N, f, cvN);
+                d3_store(P.f_geo, P.fcap, GEO_E, f, vE);
+                d3_store(P.f_geo, P.fcap, GEO_HN, f, h.n);
+                P.f_geo[(size_t)GEO_FNE * P.fcap + f] = fNE;
+                P.f_geo[(size_t)GEO_F * P.fcap + f] = F;
+                P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
+                P.f_geo[(size_t)GEO_ETA * P.fcap + f] = mp.refr / mh.refr;
+                P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
+                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh.luster;
+                spec_store(P.f_color, P.fcap, f, color);
+                t = h.t;
+                pm = h.mat;
+                break;
+            } else {
+                t = h.t;
+                pm = h.mat;
+            }
+        }
+        if (!(flags & FR_FINAL) && S.mats[pm].prop) {           /* Shade.cpp:512-516 */
+            Spec ptr, pst;
+            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), S.mats[pm].color, ptr, pst);
+            spec_store(P.f_fin, P.fcap, f, tr * pst);
+            flags |= FR_FIN;
+        }
+        spec_store(P.f_R, P.fcap, f, R);
+        spec_store(P.f_tr, P.fcap, f, tr);
+    }
+    /* append this lane's shadow rays to the queue: one atomic per wave */
+    int base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
+    if (!live) return;
+    P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
+    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
+    P.f_flags[f] = flags;
+    if (n_shadow) {
+        int k = 0;
+        for (int li = 0; li < S.n_lights; li++) {
+            if (!(mask & (1u << li))) continue;
+            int s = base + k++;
+            if (s >= P.scap) continue;          /* overflow is reported by the host from the counter */
+            const RtLightDev &l = S.lights[li];
+            D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+            if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+            d3_store(P.s_ray, P.scap, 0, s, Ppt);
+            d3_store(P.s_ray, P.scap, 3, s, lo - Ppt);
+            P.s_light[s] = li;
+            P.s_root[s] = P.f_root[f];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359 */
+__global__ void __launch_bounds__(256) k_shadow(const RtDevScene *Sp, RtPipe P, int n)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const RtDevScene &S = *Sp;
+    DRay ray;
+    ray.org = d3_fetch(P.s_ray, P.scap, 0, s);
+    ray.dir = d3_fetch(P.s_ray, P.scap, 3, s);
+    const RtLightDev &l = S.lights[P.s_light[s]];
+    double aux[6];
+    int root = P.s_root[s];
+    for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
+    double r2 = dot(ray.dir, ray.dir);
+    Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
+    Arena A;
+    int start;
+    int count = intersect_scene(S, ray, 1.0, A, start);
+    if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+    atomicAdd(&P.counters[CTR_SHADOWRAYS], 1);
+    int i = 0, pm = 0;
+    if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
+    double t = 0.0;
+    Spec tr = spec_const(1.0f);
+    bool blocked = false;
+    for (; i < count && A.h[start + i].t < 1.0 - RT_EPSILON; i++) {
+        ShadeHit h;
+        transform_normals(S, ray, A.h[start + i], h, aux);
+        const RtMaterialDev &mp = S.mats[pm], &mh = S.mats[h.mat];
+        if (mp.luster != RT_MAT_TRANSPARENT || mh.luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
+        if (mp.prop) {
+            Spec ptr, pst;
+            propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+            tr = tr * ptr;
+        }
+        if (mp.refr != mh.refr) {
+            D3 vE, cvN;
+            double fNE, F = 0.0, fNT = 0.0;
+            consistent_normal(ray, h, vE, cvN, fNE);
+            fresnel_real(fNE, mh.refr, mp.refr, F, fNT);
+            if (F == 1.0) { blocked = true; break; }
+            tr = tr * (1.0 - F);
+        }
+        t = h.t;
+        pm = h.mat;
+    }
+    Spec out;
+    if (blocked) out = spec_const(0.0f);
+    else {
+        if (S.mats[pm].prop && S.mats[pm].luster == RT_MAT_TRANSPARENT) {
+            Spec ptr, pst;
+            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), S.mats[pm].color, ptr, pst);
+            tr = tr * ptr;
+        }
+        out = E * tr;
+    }
+    spec_store(P.s_E, P.scap, s, out);
+}
+
+/* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
+__global__ void __launch_bounds__(256) k_shade(const RtDevScene *Sp, RtPipe P, int f0, int f1)
+{
+    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = f < f1;
+    const RtDevScene &S = *Sp;
+    int nchild = 0, flags = 0;
+    bool want_refl = false, want_refr = false;
+    D3 Ppt = d3(0, 0, 0), dir_refl = d3(0, 0, 0), dir_refr = d3(0, 0, 0);
+    int depth = 0;
+    if (live) {
+        flags = P.f_flags[f];
+        depth = FR_DEPTH(flags);
+        if (flags & FR_BOUNDARY) {
+            int root = P.f_root[f];
+            double uL = P.aux[(size_t)2 * P.ncap + root], vL_ = P.aux[(size_t)3 * P.ncap + root];
+            Ppt = d3_fetch(P.f_geo, P.fcap, GEO_P, f);
+            D3 cvN = d3_fetch(P.f_geo, P.fcap, GEO_N, f), vE = d3_fetch(P.f_geo, P.fcap, GEO_E, f), hn = d3_fetch(P.f_geo, P.fcap, GEO_HN, f);
+            double fNE = P.f_geo[(size_t)GEO_FNE * P.fcap + f], F = P.f_geo[(size_t)GEO_F * P.fcap + f];
+            double fNT = P.f_geo[(size_t)GEO_FNT * P.fcap + f], eta = P.f_geo[(size_t)GEO_ETA * P.fcap + f];
+            int rough = P.f_ids[(size_t)IDS_ROUGH * P.fcap + f], luster = P.f_ids[(size_t)IDS_LUSTER * P.fcap + f];
+            int base = P.f_ids[(size_t)IDS_SHBASE * P.fcap + f];
+            unsigned mask = (unsigned)P.f_ids[(size_t)IDS_SHMASK * P.fcap + f];
+            Spec color = spec_fetch(P.f_color, P.fcap, f), R = spec_fetch(P.f_R, P.fcap, f);
+            int k = 0;
+            for (int li = 0; li < S.n_lights; li++) {
+                const RtLightDev &l = S.lights[li];
+                D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+                if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * uL + d3(l.vB[0], l.vB[1], l.vB[2]) * vL_;
+                D3 dir = lo - Ppt;
+                if (dot(cvN, dir) <= 0.0 && luster != RT_MAT_TRANSPARENT) continue;
+                D3 vL = normalize(dir);
+                double fNL = dot(cvN, vL);
+                Spec Eraw;
+                if (l.no_shadow) Eraw = spec_div(spec_load(l.flux), 4.0 * RT_PI * dot(dir, dir));      /* Shade.cpp:315-318 */
+                else { Eraw = spec_fetch(P.s_E, P.scap, base + k); k++; }
+                (void)mask;
+                Spec E = Eraw * fNL;
+                if (spec_is_black(E)) continue;
+                Spec refl = brdf(rough, luster, color, hn, vL, vE, cvN, F);
+                R = R + refl * E;
+            }
+            spec_store(P.f_R, P.fcap, f, R);
+            if (rough == RT_SURF_POLISHED) {
+                int perturbed = (flags & FR_PERTURBED) ? 1 : 0;
+                if (F != 0.0 && depth + 1 < 6) {
+                    spec_store(P.f_w1, P.fcap, f, ray_reflectance(luster, color, F));
+                    flags |= FR_C1;
+                    if (depth + 1 < RT_MAX_DEPTH) { want_refl = true; dir_refl = reflect_dir(cvN, vE, hn, perturbed, fNE); nchild++; }
+                    else spec_store(P.f_c1, P.fcap, f, spec_const(0.0f));
+                }
+                if (luster == RT_MAT_TRANSPARENT && F < 1.0) {
+                    P.f_geo[(size_t)GEO_W2 * P.fcap + f] = 1.0 - F;
+                    flags |= FR_C2;
+                    if (depth + 1 < RT_MAX_DEPTH) { want_refr = true; dir_refr = refract_dir(cvN, vE, hn, perturbed, eta, fNE, fNT); nchild++; }
+                    else spec_store(P.f_c2, P.fcap, f, spec_const(0.0f));
+                }
+            }
+            P.f_flags[f] = flags;
+        }
+    }
+    int base = wave_alloc(nchild, &P.counters[CTR_FRAMES]);
+    if (!live || nchild == 0) return;
+    int c = base;
+    for (int which = 0; which < 2; which++) {
+        if (which == 0 ? !want_refl : !want_refr) continue;
+        int nf = c++;
+        if (nf >= P.fcap) continue;             /* overflow reported by the host */
+        d3_store(P.f_ray, P.fcap, 0, nf, Ppt);
+        d3_store(P.f_ray, P.fcap, 3, nf, which == 0 ? dir_refl : dir_refr);
+        P.f_parent[nf] = f;
+        P.f_root[nf] = P.f_root[f];
+        P.f_flags[nf] = FR_MAKE_DEPTH(depth + 1) | (which ? FR_SLOT2 : 0);
+    }
+}
+
+/* ------------------------------------------------------------------ k_resolve */
+__global__ void __launch_bounds__(256) k_resolve(const RtDevScene *Sp, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+{
+    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= f1) return;
+    const RtDevScene &S = *Sp;
+    int flags = P.f_flags[f];
+    Spec R = spec_fetch(P.f_R, P.fcap, f);
+    if (flags & FR_BOUNDARY) {
+        if (flags & FR_C1) R = R + spec_fetch(P.f_c1, P.fcap, f) * spec_fetch(P.f_w1, P.fcap, f);
+        if (flags & FR_C2) R = R + spec_fetch(P.f_c2, P.fcap, f) * P.f_geo[(size_t)GEO_W2 * P.fcap + f];
+        R = R * spec_fetch(P.f_tr, P.fcap, f);
+    }
+    if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
+    int parent = P.f_parent[f];
+    if (parent >= 0) {
+        spec_store((flags & FR_SLOT2) ? P.f_c2 : P.f_c1, P.fcap, parent, R);
+        return;
+    }
+    int root = P.f_root[f];
+    if (out_spec) for (int k = 0; k < RT_NSPEC; k++) out_spec[(size_t)root * RT_NSPEC + k] = R.v[k];
+    if (out_rgb) {
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        if (S.venera) {                                         /* Spectrum::vRGB, RadiometryColor.cpp:971-983 */
+            for (int i = 0; i < RT_NSPEC; i++) { r += R.v[i] * S.chan[0][i]; g += R.v[i] * S.chan[1][i]; b += R.v[i] * S.chan[2][i]; }
+        } else {                                                /* Spectrum::sRGB, RadiometryColor.h:62-66 */
+            for (int i = 0; i < RT_NSPEC; i++) {
+                double w = (double)R.v[i] * (5.0 / 10.0);
+                r = r + (float)((double)S.spec2rgb[i][0] * w);
+                g = g + (float)((double)S.spec2rgb[i][1] * w);
+                b = b + (float)((double)S.spec2rgb[i][2] * w);
+            }
+        }
+        out_rgb[(size_t)root * 3] = r; out_rgb[(size_t)root * 3 + 1] = g; out_rgb[(size_t)root * 3 + 2] = b;
+    }
+}
+
+/* ------------------------------------------------------------------ probe: raw hit lists */
+__global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, int n, const double *org, const double *dir, const double *aux6,
+                                                         int max_hits, int transform, int *out_count, double *out_t, double *out_n,
+                                                         int *out_leaf, int *out_mat, int *out_surf, int *overflow)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RtDevScene &S = *Sp;
+    DRay ray;
+    ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
+    ray.dir = d3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+    double aux[6];
+    for (int i = 0; i < 6; i++) aux[i] = aux6 ? aux6[6 * k + i] : S.aux_init[i];
+    Arena A;
+    int start;
+    int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+    if (A.overflow) atomicAdd(overflow, 1);
+    out_count[k] = count;
+    for (int i = 0; i < max_hits; i++) {
+        size_t o = (size_t)k * max_hits + i;
+        if (i < count) {
+            const HitRec &hr = A.h[start + i];
+            D3 nn = hr.n;
+            if (transform) {
+                ShadeHit h;
+                transform_normals(S, ray, hr, h, aux);
+                nn = h.perturbed ? h.np : h.n;
+            }
+            out_t[o] = hr.t;
+            out_n[3 * o] = nn.x; out_n[3 * o + 1] = nn.y; out_n[3 * o + 2] = nn.z;
+            out_leaf[o] = hr.prim == 0xFFFF ? -8 : S.prims[hr.prim].id;
+            out_mat[o] = S.mats[hr.mat].id;
+            out_surf[o] = S.surfs[hr.surf].id;
+        } else {
+            out_t[o] = 0.0; out_n[3 * o] = out_n[3 * o + 1] = out_n[3 * o + 2] = 0.0;
+            out_leaf[o] = out_mat[o] = out_surf[o] = -9;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ reconstruction
+ * FastBlueSamplingTile splats every sample bilinearly into a supersampled image (Image::FastSplatRGB,
+ * Image.cpp:1309-1334), then resamples with a separable Kaiser-windowed sinc (ImageResample,
+ * Sampling.cpp:186-234) and divides by the equally filtered weights (Image::Normalize, Image.cpp:1238-1260).
+ * A scatter with float atomics would make the float sums order dependent.  Instead every supersample
+ * pixel GATHERS its (on average four) contributions in the reference's loop order -- tile x outer, tile y
+ * inner, sample index, corner -- from a per-tile-pixel contributor table built once from the blue-noise
+ * tile, which reproduces the reference's float accumulation bit for bit and needs no atomics. */
+__global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene *Sp, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
+                                                      int y0, int y1, float *im2 /*[3][rows][nW]*/, float *wt2 /*[rows][nW]*/)
+{
+    const RtDevScene &S = *Sp;
+    int px = blockIdx.x * blockDim.x + threadIdx.x;
+    int py = y0 + blockIdx.y;
+    if (px >= g.nW || py >= y1) return;
+    float r = 0.0f, gg = 0.0f, b = 0.0f, w = 0.0f;
+    int tcx = px / RT_BLUE_NSQRT, tcy = py / RT_BLUE_NSQRT;
+    for (int tx = tcx - 1; tx <= tcx + 1; tx++) {
+        if (tx < 0 || tx >= g.tiles_x) continue;
+        int lx = px - tx * RT_BLUE_NSQRT;
+        if (lx < -1 || lx > RT_BLUE_NSQRT) continue;
+        for (int ty = tcy - 1; ty <= tcy + 1; ty++) {
+            if (ty < g.tile_y0 || ty >= g.tile_y0 + g.tiles_y_local) continue;
+            int ly = py - ty * RT_BLUE_NSQRT;
+            if (ly < -1 || ly > RT_BLUE_NSQRT) continue;
+            int cell = (ly + 1) * (RT_BLUE_NSQRT + 2) + (lx + 1);
+            int e0 = T.offsets[cell], e1 = T.offsets[cell + 1];
+            int64_t sbase = ((int64_t)tx * g.tiles_y_local + (ty - g.tile_y0)) * RT_BLUE_N;
+            for (int e = e0; e < e1; e++) {
+                int i = T.entries[e];
+                /* v = g_rgvBlueNoise[i]*BLUE_NSQRT + vTile (Sampling.cpp:501), then FastSplatRGB's own arithmetic */
+                double x = S.blue[2 * i] * (double)RT_BLUE_NSQRT + (double)tx * (double)RT_BLUE_NSQRT;
+                double y = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + (double)ty * (double)RT_BLUE_NSQRT;
+                x -= 0.5; y -= 0.5;
+                double fx = floor(x), fy = floor(y);
+                int i1 = (int)fx, j1 = (int)fy;
+                double dx = x - fx, dy = y - fy, wx, wy;
+                if (px == i1) wx = 1.0 - dx; else if (px == i1 + 1) wx = dx; else continue;
+                if (py == j1) wy = 1.0 - dy; else if (py == j1 + 1) wy = dy; else continue;
+                const float *c = sample_rgb + 3 * (sbase + i);
+                r += (float)((double)(float)((double)c[0] * wx) * wy);
+                gg += (float)((double)(float)((double)c[1] * wx) * wy);
+                b += (float)((double)(float)((double)c[2] * wx) * wy);
+                w += (float)(wx * wy);
+            }
+        }
+    }
+    size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
+    im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b;
+    wt2[o] = w;
+}
+
+/* Resample (Sampling.cpp:131-184), WRAP_CLAMP.  src: [planes][src_rows][src_n] -> dst laid out [planes][src_rows][dst_n] */
+__global__ void __launch_bounds__(256) k_resample_rows(const float *src, int planes, int rows, int n_src, int n_dst, RtTapTable T, float *dst)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = blockIdx.y;
+    int pl = blockIdx.z;
+    if (id >= n_dst || row >= rows || pl >= planes) return;
+    const float *s = src + ((size_t)pl * rows + row) * n_src;
+    int i0 = T.first[id], cnt = T.count[id];
+    const double *pf = T.taps + T.offset[id];
+    double sum = 0.0, wsum = 0.0;
+    for (int k = 0; k < cnt; k++) {
+        int is = i0 + k, i = is;
+        if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
+        double y = (double)s[i], fw = pf[k];
+        sum += fw * y;
+        wsum += fw;
+    }
+    if (wsum != 0.0) sum /= wsum;
+    dst[((size_t)pl * rows + row) * n_dst + id] = (float)sum;
+}
+
+/* vertical pass: src [planes][src_rows_local][width] (rows src_y0..), dst rows [row0,row1) of [planes][H][width] */
+__global__ void __launch_bounds__(256) k_resample_cols(const float *src, int planes, int src_rows_local, int src_y0, int n_src_total, int width,
+                                                       int row0, int row1, RtTapTable T, float *dst, size_t dst_plane_stride)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = row0 + blockIdx.y;
+    int pl = blockIdx.z;
+    if (i >= width || j >= row1 || pl >= planes) return;
+    int j0 = T.first[j], cnt = T.count[j];
+    const double *pf = T.taps + T.offset[j];
+    double sum = 0.0, wsum = 0.0;
+    for (int k = 0; k < cnt; k++) {
+        int js = j0 + k, jj = js;
+        if ((unsigned)js >= (unsigned)n_src_total) jj = js < 0 ? 0 : n_src_total - 1;
+        double y = (double)src[((size_t)pl * src_rows_local + (size_t)(jj - src_y0)) * width + i], fw = pf[k];
+        sum += fw * y;
+        wsum += fw;
+    }
+    if (wsum != 0.0) sum /= wsum;
+    dst[(size_t)pl * dst_plane_stride + (size_t)j * width + i] = (float)sum;
+}
+
+/* Image::Normalize (Image.cpp:1238-1260) on rows [row0,row1) */
+__global__ void __launch_bounds__(256) k_normalize(float *planes, const float *wt, int width, int height, int row0, int row1)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = row0 + blockIdx.y;
+    if (i >= width || j >= row1) return;
+    float w = wt[(size_t)j * width + i];
+    if (w != 0.0f)
+        for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] /= w;
+}
+
+/* TestSamplingTile: one sample per pixel, SetRGB (Sampling.cpp:335-346) */
+__global__ void __launch_bounds__(256) k_store_test(const float *sample_rgb, int width, int height, int row0, int row1, float *planes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = row0 + blockIdx.y;
+    if (i >= width || j >= row1) return;
+    const float *c = sample_rgb + 3 * ((size_t)(j - row0) * width + i);
+    for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] = c[k];
+}
+
+#include "rt_api.inc"

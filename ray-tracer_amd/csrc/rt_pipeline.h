@@ -1,0 +1,58 @@
+/* rt_pipeline.h -- HBM-resident state of the wavefront pipeline (rt_kernels.hip) and of reconstruction. */
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+/* frame flags */
+#define FR_BOUNDARY   1        /* the walk stopped at a boundary: R is multiplied by tr on resolve (Shade.cpp:503) */
+#define FR_C1         2        /* has a reflection term (child frame or black) */
+#define FR_C2         4        /* has a refraction term */
+#define FR_FIN        8        /* has a trailing propagator sterisent term (Shade.cpp:512-516) */
+#define FR_FINAL      16       /* MAT_NOSHADE early return: R is the result */
+#define FR_SLOT2      32       /* this frame is its parent's refraction child */
+#define FR_PERTURBED  64
+#define FR_DEPTH(f)        (((f) >> 8) & 0xFF)
+#define FR_MAKE_DEPTH(d)   (((d) & 0xFF) << 8)
+#define FR_KEEP_MASK       (0xFF00 | FR_SLOT2)
+
+enum { GEO_P = 0, GEO_N = 3, GEO_E = 6, GEO_HN = 9, GEO_FNE = 12, GEO_F = 13, GEO_FNT = 14, GEO_ETA = 15, GEO_W2 = 16, GEO_COUNT = 17 };
+enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT = 4 };
+enum { CTR_FRAMES = 0, CTR_SHADOW = 1, CTR_OVERFLOW = 2, CTR_PRIMARY = 3, CTR_SECONDARY = 4, CTR_SHADOWRAYS = 5, CTR_COUNT = 8 };
+
+typedef struct RtPipe {
+    int     fcap, scap, ncap;   /* frame, shadow-ray and root capacities */
+    int     pad_;
+    /* frames, SoA [field][fcap] */
+    double *f_ray;              /* 6 */
+    int    *f_parent, *f_root, *f_flags;
+    float  *f_R, *f_tr, *f_color, *f_c1, *f_c2, *f_w1, *f_fin;     /* 10 each */
+    double *f_geo;              /* GEO_COUNT */
+    int    *f_ids;              /* IDS_COUNT */
+    double *aux;                /* 6 x ncap: the six distributed-sampling dimensions per root sample */
+    /* shadow rays, SoA [field][scap] */
+    double *s_ray;              /* 6 */
+    int    *s_light, *s_root;
+    float  *s_E;                /* 10 */
+    int    *counters;           /* CTR_COUNT */
+} RtPipe;
+
+typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
+    int     sampler;
+    int     width, height;      /* output image */
+    int     nW, nH;             /* supersampled image (FASTBLUE), Sampling.cpp:484-485 */
+    int     tiles_x, tiles_y;   /* 40x40 blue-noise tiles covering it, Sampling.cpp:498-499 */
+    int     tile_y0, tiles_y_local;     /* tile rows traced by this call (row sharding) */
+    int     test_row0, test_rows;       /* TEST sampler: output rows traced by this call */
+    int     pad_;
+    double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
+} RtSampleGrid;
+
+typedef struct RtSplatTable {   /* contributors of each pixel of a (40+2)^2 tile neighbourhood, CSR */
+    const int *offsets;         /* 42*42 + 1 */
+    const int *entries;         /* candidate sample indices, ascending = the reference's splat order */
+} RtSplatTable;
+
+typedef struct RtTapTable {     /* ComputeTaps / Resample, Sampling.cpp:86-184 */
+    const double *taps;
+    const int    *first, *count, *offset;
+} RtTapTable;

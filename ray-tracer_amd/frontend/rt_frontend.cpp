@@ -230,6 +230,7 @@ Matrix3 InverseMatrix(const Matrix3 &a)                                         
 /* -------------------------------------------------------------------------------- solids ---- */
 static int s_serial = 0;
 Solid::Solid() : nIsAffine(0), nSerial(s_serial++) {}
+void rt_frontend_reset_ids() { s_serial = 0; }
 
 #define T_  1.0 / D_SQRT3
 #define P1_ D_PHI / D_SQRT3

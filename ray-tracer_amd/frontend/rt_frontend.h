@@ -538,3 +538,4 @@ struct RtSceneBlob {                            /* owns every array an RtSceneDe
 };
 int  rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen);
 const char *rt_frontend_last_error();
+void rt_frontend_reset_ids();             /* restart the RtNode.id serial (ids are per scene build) */

@@ -395,6 +395,7 @@ extern "C" const char *rtf_last_error() { return s_scene_err[0] ? s_scene_err : 
    optimize != 0 calls psModel->Optimize() before flattening (what every reference driver does). */
 extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int optimize)
 {
+    rt_frontend_reset_ids();
     rtf_scene *s = new rtf_scene;
     s_scene_err[0] = 0;
     std::string name(spec);

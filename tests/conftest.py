@@ -1,0 +1,72 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def entry():
+    import __graft_entry__ as g
+    return g
+
+
+@pytest.fixture(scope="session")
+def rt(entry):
+    """ray-tracer_amd package (ctypes bindings of the C ABI and of the host front end)."""
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle(entry):
+    """CPU oracle binding -- test infrastructure only."""
+    return entry.load_oracle()
+
+
+SCENE_GLASS = """(scene
+ (model (makeunion
+   (translate -1.2 0 0 (material 0.9 1.474 (scale g_sEmerald 0.01) transparent none coloredglass (surface polished none (sphere))))
+   (translate 1.3 0.2 -0.5 (rotate 0.3 0.5 0.1 (material 0.7 1.333 g_sWater transparent none coloredglass (surface polished none (cube)))))
+   (translate 0 -0.3 -2.5 (material 0.9 auto g_sGold gold none none (surface polished none (scale 1.5 1.5 1.5 (sphere)))))
+   (translate 0 2.2 -1 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 9 -6.5 12 (scale (blackbody 6500) 8000))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 2000))
+ (camera stereographic 0 0 8 70)
+ (sampler fastblue))"""
+
+SCENE_BUMPY = """(scene
+ (model (makeunion
+   (translate -1.5 0 0 (rotate 0.2 0.4 0 (surface shiny bumpy (material 0.9 auto g_sRed plastic none none (torus 0.4)))))
+   (translate 1.5 0 0 (surface wet microfacets (material 0.9 auto g_sCopper metal none none (scale 1 1.3 1 (sphere)))))
+   (translate 0 -1.8 0 (surface smooth none (material 0.9 auto g_sBlue plastic faceted20 none (dodecahedron))))
+   (translate 0 1.6 0.5 (surface polished quasimicrofacet (material 0.9 auto g_sSilverRefraction silver none none (cylinder))))
+   (translate 0 3.2 -1 (scale 9 0.2 9 (surface burnished fibers (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
+ (camera aperture 2.0 8 0 0 8 50)
+ (sampler fastblue 0))"""
+
+SCENE_CSG = """(scene
+ (model (union
+   (surface burnished none (makeunion
+     (translate -2 -2 0 (material 0.9 auto g_sRed metal none none (difference (cube) (scale 0.5 0.5 1.2 (cylinder)))))
+     (translate 2 -2 0 (material 0.5 auto g_sGreen plastic none none (intersection (sphere) (hyperboloid1 0.125))))
+     (translate -2 2 0 (rotate 0.4 0.2 0 (material 0.9 auto g_sYellow metal none none (union (torus 0.3) (scale 0.6 0.6 0.6 (sphere))))))
+     (translate 2 2 0 (material 0.9 auto g_sCyan plastic none none (boundingbox (knoboid 0.5 1.0))))
+     (translate 0 0 0 (rotate 0.5 0.5 0 (material 0.7 auto g_sOrange metal none none (angularclip 0.3 2.5 (torus 0.35)))))
+     (translate 0 -3.5 0 (scale 0.7 0.7 0.7 (material 0.9 auto g_sMagenta plastic none none (icosahedroncage 0.05 0.1))))
+     (translate 0 3.5 0 (scale 0.6 0.6 0.6 (material 0.9 auto g_sWhite plastic none none (cuboid 0.2 1 1 1))))))
+   (translate 0 5.25 -10 (scale 12 1 12 (cube)))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
+ (pointlight -10 -10 -10 (scale (blackbody 6500) 500))
+ (camera stereographic 0 0 9 70)
+ (sampler fastblue))"""

@@ -1,0 +1,160 @@
+"""CPU tests (no GPU): the oracle against the reference's own golden data, the host front end, and the
+C-ABI library's symbol table.  Run with -m "not gpu"."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_quasi_index_matches_reference_tables(rt, oracle):
+    """BuildQuasiIndex (Patterns.cpp:1723-1736) vs the reference's checked-in outputs
+    (LowDiscrepancy.cpp:262-333, BlueNoiseTile.cpp:1607-2417): oracle AND product, bit exact."""
+    tabs = json.load(open(os.path.join(GOLD, "quasi_index_tables.json")))["tables"]
+    assert len(tabs) == 8
+    for key, want in tabs.items():
+        p = int(re.search(r"_p(\d+)_", key).group(1))
+        n = int(re.search(r"_N(\d+)$", key).group(1))
+        want = np.array(want, dtype=np.int32)
+        assert (oracle.build_quasi_index(p, n) == want).all(), key
+        assert (rt.build_quasi_index(p, n) == want).all(), key
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 16, 125, 1000])
+def test_quasi_index_is_permutation(rt, oracle, n):
+    for p in (2, 3, 5, 7):
+        a = rt.build_quasi_index(p, n)
+        assert sorted(a.tolist()) == list(range(n))
+        assert (a == oracle.build_quasi_index(p, n)).all()
+
+
+def test_mwc_generator_product_vs_oracle(rt, oracle):
+    """RandomUnsigned (MonteCarlo.h:17-27), default seeds (MonteCarlo.cpp:9-10): integer, bit exact."""
+    n = 4096
+    st1 = np.array([886459, 361290869], dtype=np.uint32)
+    st2 = st1.copy()
+    a = np.zeros(n, dtype=np.uint32)
+    b = np.zeros(n, dtype=np.uint32)
+    rt.rt_lib().rt_random_unsigned(st1.ctypes.data_as(C.POINTER(C.c_uint32)), n, a.ctypes.data_as(C.POINTER(C.c_uint32)))
+    oracle.lib().orc_random_unsigned(st2.ctypes.data_as(C.POINTER(C.c_uint32)), n, b.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert (a == b).all() and (st1 == st2).all()
+    # first value by hand: (1965537969 * 886459 + 361290869) mod 2^32
+    assert int(a[0]) == (1965537969 * 886459 + 361290869) & 0xFFFFFFFF
+    # RandomDouble of the front end = (hi + lo/2^32)/2^32 of consecutive draws
+    d = np.zeros(8)
+    rt.frontend_lib().rtf_random_double(886459, 361290869, 8, d.ctypes.data_as(C.POINTER(C.c_double)))
+    want = (a[0:16:2].astype(np.float64) + a[1:16:2].astype(np.float64) * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0)
+    assert (d == want).all()
+
+
+SURVEY = json.load(open(os.path.join(GOLD, "survey_checksums.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", [c for c in SURVEY if c["spp"] == 1], ids=lambda c: "%s_%d_%dspp" % (c["scene"], c["width"], c["spp"]))
+def test_oracle_reproduces_reference_checksums_1spp(rt, oracle, case):
+    """The oracle (own Optimize + recursive tracer) on the scenes built by the front end vs the image
+    checksums and ray counts the survey recorded from the reference itself."""
+    _check_case(rt, oracle, case)
+
+
+@pytest.mark.parametrize("case", [c for c in SURVEY if c["spp"] == 16 and c["scene"] == "S1"], ids=lambda c: "%s_%d_%dspp" % (c["scene"], c["width"], c["spp"]))
+def test_oracle_reproduces_reference_checksums_fastblue(rt, oracle, case):
+    _check_case(rt, oracle, case)
+
+
+def _check_case(rt, oracle, case):
+    fs = rt.FrontScene(case["scene"], case["sampler"], optimize=False)
+    osc = oracle.OracleScene(fs.desc)
+    assert osc.check_bounding_boxes() == 0
+    rd = rt.RtRenderDesc(case["width"], case["height"], float(case["spp"]), 0, 0)
+    st = rt.RtStats()
+    img, _, n = osc.render(case["width"], case["height"], case["spp"], rd, st, threads=8)
+    assert abs(float(img.astype(np.float64).sum()) - case["sum"]) < 1e-6
+    if case["rays"] is not None:
+        assert st.rays() == case["rays"]
+
+
+def test_oracle_threads_do_not_change_the_image(rt, oracle):
+    fs = rt.FrontScene("S1", "fastblue", optimize=False)
+    osc = oracle.OracleScene(fs.desc)
+    rd = rt.RtRenderDesc(48, 40, 4.0, 0, 0)
+    a, _, _ = osc.render(48, 40, 4, rd, rt.RtStats(), threads=1)
+    b, _, _ = osc.render(48, 40, 4, rd, rt.RtStats(), threads=5)
+    assert (a == b).all()
+
+
+def test_frontend_optimize_matches_oracle_optimize(rt, oracle, ):
+    """Front end's Optimize() (affine chain merge, Solids.cpp:957-983) vs the oracle's own: identical hit lists."""
+    from conftest import SCENE_CSG
+    raw = rt.FrontScene(SCENE_CSG, "test", optimize=False)
+    opt = rt.FrontScene(SCENE_CSG, "test", optimize=True)
+    assert opt.desc.contents.n_nodes < raw.desc.contents.n_nodes      # chains were merged
+    a = oracle.OracleScene(raw.desc, run_optimize=True)
+    b = oracle.OracleScene(opt.desc, run_optimize=False)
+    rng = np.random.default_rng(5)
+    n = 4000
+    org = np.tile(np.array([0.0, 0.0, 9.0]), (n, 1)) + rng.normal(0, 0.05, (n, 3))
+    dr = np.concatenate([rng.uniform(-0.6, 0.6, (n, 2)), -np.ones((n, 1))], axis=1)
+    ra = a.intersect(org, dr, max_hits=12, transform=1)
+    rb = b.intersect(org, dr, max_hits=12, transform=1)
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x, y)
+    assert ra[0].max() >= 4
+
+
+def test_extents_follow_reference_quirks(rt):
+    """GetExtent of the front end: TestExtents cases (Test.cpp:1557-1581)."""
+    L = rt.frontend_lib()
+    out = np.zeros(6)
+
+    def ext(txt):
+        assert L.rtf_extent(txt.encode(), out.ctypes.data_as(C.POINTER(C.c_double))) == 0, L.rtf_last_error()
+        return out.copy()
+    assert (ext("(icosahedron)") == [-1, -1, -1, 1, 1, 1]).all()          # unit cube regardless (Solids.cpp:789)
+    assert (ext("(torus 0.5)") == [-1.5, -1.5, -0.5, 1.5, 1.5, 0.5]).all()
+    assert (ext("(translate 0 3 0 (scale 1 5 1 (sphere)))") == [-1, -2, -1, 1, 8, 1]).all()
+    assert (ext("(intersection (sphere) (translate 0 1 0 (sphere)))") == [-1, 0, -1, 1, 1, 1]).all()
+    assert (ext("(boundingbox (union (sphere) (translate 0 3 0 (sphere))))") == [-1, -1, -1, 1, 4, 1]).all()
+
+
+def test_test_material_hit_lists(rt, oracle):
+    """TestMaterial (Test.cpp:1242-1271): (t, density) lists of union / intersection / difference of a
+    rotated torus (density 0.9) and a sphere (0.5) along the ray (0,0,-5) -> (0,0,1)."""
+    body = "(material 0.9 auto g_sYellow plastic none none (rotate 1.5707963267948966 0 0 (torus 0.5))) (material 0.5 auto g_sBlue plastic none none (sphere))"
+    org = np.array([[0.0, 0.0, -5.0]])
+    dr = np.array([[0.0, 0.0, 1.0]])
+    got = {}
+    for op in ("union", "intersection", "difference"):
+        fs = rt.FrontScene("(scene (model (%s %s)))" % (op, body), "test", optimize=False)
+        ids = {fs.desc.contents.nodes[i].id: fs.desc.contents.data[fs.desc.contents.nodes[i].data]
+               for i in range(fs.desc.contents.n_nodes) if fs.desc.contents.nodes[i].type == 12}
+        ids[-1] = 0.0
+        cnt, t, _, _, mat, _ = oracle.OracleScene(fs.desc).intersect(org, dr, max_hits=8)
+        got[op] = [(round(float(t[0, k]), 9), ids[int(mat[0, k])]) for k in range(cnt[0])]
+    assert got["union"] == [(3.5, 0.9), (4.5, 0.5), (5.5, 0.9), (6.5, 0.0)]
+    assert got["intersection"] == [(4.0, 0.5), (4.5, 0.0), (5.5, 0.5), (6.0, 0.0)]
+    assert got["difference"] == [(3.5, 0.9), (4.0, 0.0), (6.0, 0.9), (6.5, 0.0)]
+
+
+def test_c_abi_exports_every_declared_symbol(rt):
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    names = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", hdr))
+    assert {"rt_render", "rt_render_device", "rt_scene_upload", "rt_scene_free", "rt_last_error"} <= names
+    L = rt.rt_lib()
+    for n in sorted(names):
+        assert hasattr(L, n), n
+
+
+def test_upload_without_gpu_fails_loudly(rt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    fs = rt.FrontScene("S1", "test", optimize=True)
+    with pytest.raises(rt.RtError) as e:
+        rt.GpuScene(fs.desc)
+    assert "no HIP device" in str(e.value) or "CPU path" in str(e.value)
