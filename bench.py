@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the render hot path on MI355X.
+
+A "step" is one RayTracer::Render of the workload: sample generation, camera rays, CSG intersection,
+shading with shadow / secondary rays and reconstruction, with the scene already resident in HBM and the
+image left in HBM (rt_render_device).  At N > 1 the image rows are split across ranks (no data-path
+collective; the finished row bands are gathered to rank 0 with RCCL, inside the timed region).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S0|S1|S2] [--width W --height H --spp S]
+                  [--no-cpu-baseline]
+
+Default workload = BASELINE.json configs[1]: the as-checked-in TestScene.cpp scene ("S0": 257 spheres,
+MakeLightsLorenz, stereographic camera) at 3840x2160, 64 spp FastBlue = 530,841,600 samples.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work of the dominant kernel (k_visual), SURVEY.md section 8d weights, flops per event
+W_AFFINE, W_QUADRIC, W_BOX, W_MERGE, W_SHADE, W_SHADE_LIGHT = 33.0, 57.0, 30.0, 6.0, 250.0, 60.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = half of the 157.3 TF FP32 vector peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="S0")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=float, default=64.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    W, H, spp = args.width, args.height, args.spp
+    fs = rt.FrontScene(args.scene, "fastblue", optimize=True)
+    gs = rt.GpuScene(fs.desc)
+    # contiguous row bands; every rank traces its own halo, so the data path has no exchange
+    rows = [(H * r) // world for r in range(world + 1)]
+    row0, row1 = rows[rank], rows[rank + 1]
+    planes = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    maxrows = max(rows[r + 1] - rows[r] for r in range(world))
+
+    def step():
+        st = gs.render_device(W, H, spp, planes.data_ptr(), stream, row0, row1 if world > 1 else 0)
+        if world > 1:
+            band = torch.zeros((3, maxrows, W), dtype=torch.float32, device="cuda")
+            band[:, : row1 - row0, :] = planes[:, row0:row1, :]
+            out = [torch.empty_like(band) for _ in range(world)] if rank == 0 else None
+            dist.gather(band, out, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    planes[:, rows[r]:rows[r + 1], :] = out[r][:, : rows[r + 1] - rows[r], :]
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    rt.rt_lib().rt_set_option(b"time_kernels", 1)      # HIP events around every k_visual launch of the timed region
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    rays = samples = 0
+    t_trace = 0.0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays()
+        samples += st.samples
+        t_trace += st.seconds_trace
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    rt.rt_lib().rt_set_option(b"time_kernels", 0)
+    tot = torch.tensor([float(rays), float(samples), dt, t_trace], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[2])
+    rays_all, samples_all = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        res = {
+            "metric": "rays/sec (primary+secondary)", "value": rays_all / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64)" % (args.scene, W, H, spp),
+                       "scene": args.scene, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
+                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world},
+            "sec_per_frame": dt / args.steps,
+        }
+        res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total):
+    """Dominant kernel = k_visual (intersection + boundary shading of every visual ray).  achieved =
+    algorithmic flops per launch / average launch duration, both measured here: the kernel is timed with
+    HIP events on its own stream by re-running one chunk through the parity probe path, and the flops are
+    SURVEY 8d's per-event weights times the IDEAL-culling event counts (leaf tests = leaves whose own box
+    the ray touches), counted by the device on a sample of the workload's own camera rays."""
+    _, _, total = gs.samples(W, H, spp, 0, 0)
+    ntile = total // 1600
+    picks = sorted(set(int(x) for x in np.linspace(0, ntile - 1, 64)))
+    s8 = np.concatenate([gs.samples(W, H, spp, t * 1600, 1600)[0] for t in picks], axis=0)
+    m = len(s8)
+    org, dr = gs.camera(s8[:, :2], s8[:, 2:])
+    work = np.zeros(8, dtype=np.float64)
+    L = rt.rt_lib()
+    L.rt_probe_work.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rc = L.rt_probe_work(gs.h, m, org.ctypes.data_as(C.POINTER(C.c_double)), dr.ctypes.data_as(C.POINTER(C.c_double)), work.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc:
+        return {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "note": "rt_probe_work failed: %s" % L.rt_last_error().decode()}
+    leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch = work
+    per_ray = (leaf * (W_AFFINE + W_QUADRIC) + boxes_ideal * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
+    flops = per_ray * rays_per_launch
+    ach = flops / (ms_per_launch * 1e-3) / 1e12
+    return {"bound": "valu_fp64", "kernel": "k_visual", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+            "flops_per_ray": per_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch,
+            "events_per_ray": {"leaf_tests": leaf / m, "ideal_box_tests": boxes_ideal / m, "merged_hits": merged / m,
+                               "shaded_boundaries": boundaries / m, "light_terms": lights / m}}
+
+
+def cpu_baseline(ge, rt, scene):
+    """The oracle (CPU port of the reference's algorithm, oracle/) timed on this host: a bounded sample of the
+    same workload -- the same scene and sampler at 256x144, 16 spp (same rays per sample) -- on 1 thread."""
+    ob = ge.load_oracle()
+    raw = rt.FrontScene(scene, "fastblue", optimize=False)
+    osc = ob.OracleScene(raw.desc)
+    w, h, spp = (160, 90, 16) if scene == "S0" else (256, 144, 16)
+    rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
+    st = rt.RtStats()
+    t0 = time.perf_counter()
+    osc.render(w, h, spp, rd, st, threads=1)
+    dt = time.perf_counter() - t0
+    return {"value": st.rays() / dt, "unit": "rays/s", "cores": 1, "kind": "port",
+            "sample": "%s %dx%d %d spp FastBlue, %d rays in %.1f s, single thread (the reference is single-threaded)" % (scene, w, h, spp, st.rays(), dt)}
+
+
+if __name__ == "__main__":
+    main()

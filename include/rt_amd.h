@@ -75,8 +75,14 @@ int  rt_probe_sample_rgb(rt_scene *s, const RtRenderDesc *rd, float *out_rgb, in
 void rt_build_quasi_index(int *out, int prime, int n);
 void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);
 
+/* Measurement support for bench.py (no counterpart in the reference): sums over n rays of the ideal-culling
+   event counts of SURVEY.md section 8d (leaf tests, affine transforms, box tests, merged hits, shaded
+   boundaries, light terms), then the average duration (ms, HIP events on the render stream) and size (rays)
+   of the k_visual launches made since the previous call while option "time_kernels" was 1. */
+int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out8);
+
 /* Tunables (no counterpart in the reference).  name: "hit_arena" (hits per ray, default 48),
-   "chunk_samples" (samples per wavefront pass), "bvh" (0/1). */
+   "chunk_samples" (samples per wavefront pass), "bvh" (0/1: culling boxes), "time_kernels" (0/1). */
 int  rt_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -192,7 +192,7 @@ struct HitRec {
     D3       n;
     uint32_t leaf_affine;   /* index + 1, 0 = none */
     uint16_t surf, mat;
-    uint16_t prim;          /* primitive index, 0xFFFF = AngularClip wedge */
+    uint16_t prim;          /* primitive index, or 0x8000 | clip index for an AngularClip wedge */
     uint8_t  ntex;
     uint8_t  tex[RT_MAX_TEX];
 };
@@ -580,7 +580,7 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
             clip_plane(rs[depth], d3(c.cv1[0], c.cv1[1], c.cv1[2]), w, 0, 0.0);
             clip_plane(rs[depth], d3(c.cv2[0], c.cv2[1], c.cv2[2]), w, 1, 0.0);
             int before = A.nlist;
-            hit_list(w, A, 2 * in.b + 1, 0xFFFF, c.leaf_affine);
+            hit_list(w, A, 2 * in.b + 1, (uint16_t)(0x8000 | in.a), c.leaf_affine);
             if (A.nlist > before) merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
             else {
                 /* Merge(body, empty): every body hit is still filtered through op(pmLeft, vacuum) */

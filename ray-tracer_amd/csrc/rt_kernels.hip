@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, i
             }
             out_t[o] = hr.t;
             out_n[3 * o] = nn.x; out_n[3 * o + 1] = nn.y; out_n[3 * o + 2] = nn.z;
-            out_leaf[o] = hr.prim == 0xFFFF ? -8 : S.prims[hr.prim].id;
+            out_leaf[o] = (hr.prim & 0x8000) ? S.clips[hr.prim & 0x7FFF].id : S.prims[hr.prim].id;
             out_mat[o] = S.mats[hr.mat].id;
             out_surf[o] = S.surfs[hr.surf].id;
         } else {
@@ -455,6 +455,40 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, i
             out_leaf[o] = out_mat[o] = out_surf[o] = -9;
         }
     }
+}
+
+/* ------------------------------------------------------------------ probe: ideal-culling event counts (bench.py roofline)
+ * Counts, for each ray, the events of the IDEAL-culling algorithm of SURVEY.md section 8d: a primitive is
+ * tested only if the ray touches that primitive's own box; the box tests are those of a balanced hierarchy
+ * over the leaves (2 per level on the way down plus 2 per leaf reached). */
+__global__ void __launch_bounds__(256) k_probe_work(const RtDevScene *Sp, int n, const double *org, const double *dir, unsigned long long *out /*6*/)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const RtDevScene &S = *Sp;
+    DRay ray;
+    ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
+    ray.dir = d3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+    unsigned leaf = 0, nleaves = 0;
+    for (int pc = 0; pc < S.n_prog; pc++) {
+        int op = S.prog[pc].op;
+        if (op < OP_QUADRIC || op > OP_TORUS) continue;
+        nleaves++;
+        bool hit = true;
+        if (pc > 0 && S.prog[pc - 1].op == OP_BOUND) hit = cull_box_hit(S.boxes[S.prog[pc - 1].a], ray, RT_INFINITY);
+        if (hit) leaf++;
+    }
+    unsigned levels = 0;
+    while ((1u << levels) < nleaves) levels++;
+    Arena A;
+    int start;
+    int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+    atomicAdd(&out[0], (unsigned long long)leaf);
+    atomicAdd(&out[1], (unsigned long long)leaf);
+    atomicAdd(&out[2], (unsigned long long)(2 * levels + 2 * leaf));
+    atomicAdd(&out[3], (unsigned long long)(2 * leaf));
+    atomicAdd(&out[4], (unsigned long long)(count > 0 ? 1 : 0));
+    atomicAdd(&out[5], (unsigned long long)(count > 0 ? S.n_lights : 0));
 }
 
 /* ------------------------------------------------------------------ reconstruction

@@ -73,7 +73,7 @@ def test_hit_lists_match_oracle(gpu, oracle, scene, exact):
     """a4-a10: full hit lists (count, t, primitive id, material id, surface id, object-space normal)."""
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
     rng = np.random.default_rng(7)
-    org, dr = _rays(rng, 30000, 9.0 if scene is SCENE_CSG else 8.0)
+    org, dr = _rays(rng, 30000, 9.0 if scene is SCENE_CSG else 8.0, 0.15 if scene == "S0" else 0.7)
     gc, gt, gn, gl, gm, gs = g.intersect(org, dr, max_hits=12)
     oc, ot, on, ol, om, osf = o.intersect(org, dr, max_hits=12)
     assert (oc > 0).mean() > 0.2
@@ -122,7 +122,7 @@ def test_radiance_matches_oracle(gpu, oracle, scene, tol):
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
     rng = np.random.default_rng(11)
     n = 20000
-    org, dr = _rays(rng, n, 9.0 if scene in (SCENE_CSG, "S2") else 8.0, 0.6)
+    org, dr = _rays(rng, n, 9.0 if scene in (SCENE_CSG, "S2") else 8.0, 0.15 if scene == "S0" else 0.6)
     aux = rng.uniform(-1, 1, (n, 6))
     a = g.radiance(org, dr, aux)
     b = o.radiance(org, dr, aux)
