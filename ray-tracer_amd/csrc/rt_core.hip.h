@@ -201,6 +201,8 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     HitRec   h[RT_ARENA];
     uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
     int32_t  l_tag[RT_LIST_STACK];
+    int32_t  l_gap[RT_LIST_STACK];      /* union regions: LCA depth between this entry and the one below it */
+    uint16_t l_idx[RT_LIST_STACK];      /* union regions: last region child merged into this entry */
     int      nlist;
     int      top;           /* first free hit slot */
     int      overflow;
@@ -472,7 +474,9 @@ __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
     A.nlist -= 2;
     A.top = ls;
     if (nout > 0) {
+        /* the merged entry keeps the left operand's l_gap and takes the right operand's l_idx */
         A.l_start[A.nlist] = (uint16_t)ls; A.l_count[A.nlist] = (uint16_t)nout; A.l_tag[A.nlist] = tag;
+        A.l_idx[A.nlist] = A.l_idx[A.nlist + 1];
         A.nlist++;
         A.top = ls + nout;
     }
@@ -485,9 +489,53 @@ RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.l_start[A.nlist]; }
 /* ================================================================== the per-ray stack machine
  * Evaluates psModel->Intersect(ray) (RayTracer2020.h:72): returns the hit list as [start, start+count)
  * in the arena.  tmax bounds the culling tests only (shadow rays stop at t = 1, Shade.cpp:328). */
+struct RegionFrame {
+    int      region, ncand, pos, base_lists, nl_before, out_tag;
+    uint16_t cand[RT_MAX_CAND];
+};
+
+/* min of lca[a .. b-1], a < b (RtRegion sparse table) */
+RT_DEV int region_gap(const RtDevScene &S, const RtRegion &rg, int a, int b)
+{
+    int len = b - a, l = 31 - __clz(len);
+    const int32_t *row = S.region_lca + rg.lca0 + (size_t)l * rg.n_children;
+    int x = row[a], y = row[b - (1 << l)];
+    return x < y ? x : y;
+}
+
+/* candidates of a union region: children with unbounded boxes plus those whose box the ray touches,
+   ascending (= the reference's evaluation order) */
+__device__ int region_candidates(const RtDevScene &S, const RtRegion &rg, const DRay &wray, double tmax, uint16_t *cand, int &overflow)
+{
+    int n = 0;
+    for (int k = 0; k < rg.n_always; k++) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)S.region_always[rg.always0 + k]; else overflow = 1; }
+    if (rg.bvh_root >= 0) {
+        int stack[48], sp = 0;
+        stack[sp++] = rg.bvh_root;
+        while (sp > 0) {
+            const RtBvhNode &nd = S.bvh[stack[--sp]];
+            RtBox b;
+            for (int d = 0; d < 3; d++) { b.lo[d] = nd.lo[d]; b.hi[d] = nd.hi[d]; }
+            if (!cull_box_hit(b, wray, tmax)) continue;
+            if (nd.left < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~nd.left); else overflow = 1; }
+            else if (sp + 2 <= 48) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+            else overflow = 1;
+        }
+    }
+    for (int i = 1; i < n; i++) {           /* insertion sort: n is small */
+        uint16_t v = cand[i];
+        int j = i - 1;
+        while (j >= 0 && cand[j] > v) { cand[j + 1] = cand[j]; j--; }
+        cand[j + 1] = v;
+    }
+    return n;
+}
+
 __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
+    RegionFrame rf[RT_MAX_REGION_DEPTH];
+    int nrf = 0;
     int depth = 0;
     rs[0] = wray;
     A.nlist = 0; A.top = 0; A.overflow = 0;
@@ -572,6 +620,45 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
         case OP_SKIP_EMPTY:
             if (!top_is(A, 2 * in.a)) pc = in.b;
             break;
+        case OP_REGION: {
+            const RtRegion &rg = S.regions[in.a];
+            if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow = 1; pc = rg.end_pc; break; }
+            RegionFrame &f = rf[nrf];
+            int ov = 0;
+            f.ncand = region_candidates(S, rg, wray, tmax, f.cand, ov);
+            if (ov) A.overflow = 1;
+            if (f.ncand == 0) { pc = rg.end_pc; break; }
+            f.region = in.a; f.pos = 0; f.base_lists = A.nlist; f.nl_before = A.nlist; f.out_tag = in.tag;
+            nrf++;
+            pc = S.region_child_pc[rg.child_pc0 + f.cand[0]];
+            break;
+        }
+        case OP_RET: {
+            /* one region child done: fold the non-empty lists in the union tree's own order */
+            RegionFrame &f = rf[nrf - 1];
+            const RtRegion &rg = S.regions[f.region];
+            const int ctag = 2 * rg.uid;
+            int c = f.cand[f.pos];
+            if (A.nlist > f.nl_before) {            /* the child left a list on top */
+                int e = A.nlist - 1;
+                A.l_idx[e] = (uint16_t)c;
+                A.l_gap[e] = (e > f.base_lists) ? region_gap(S, rg, A.l_idx[e - 1], c) : -1;
+            }
+            f.pos++;
+            if (f.pos < f.ncand) {
+                int next = f.cand[f.pos];
+                while (A.nlist - f.base_lists >= 2 && A.l_gap[A.nlist - 1] > region_gap(S, rg, A.l_idx[A.nlist - 1], next))
+                    merge_top(A, MERGE_MAX, S.mats, ctag);
+                f.nl_before = A.nlist;
+                pc = S.region_child_pc[rg.child_pc0 + next];
+            } else {
+                while (A.nlist - f.base_lists >= 2) merge_top(A, MERGE_MAX, S.mats, ctag);
+                if (A.nlist - f.base_lists == 1) A.l_tag[A.nlist - 1] = f.out_tag;
+                nrf--;
+                pc = rg.end_pc;
+            }
+            break;
+        }
         case OP_ANGCLIP: {                                      /* AngularClip::Intersect, Solids.cpp:1224-1241 */
             if (!top_is(A, 2 * in.b)) break;
             const RtClip &c = S.clips[in.a];

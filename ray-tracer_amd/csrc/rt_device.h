@@ -24,6 +24,9 @@
 #define RT_ARENA            64      /* working hits per ray (private memory) */
 #define RT_MAX_LIGHTS       8
 #define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
+#define RT_MAX_CAND         64      /* children of one union region whose boxes a ray may touch */
+#define RT_MAX_REGION_DEPTH 4       /* nested union regions */
+#define RT_REGION_MIN       4       /* unions of fewer children stay plain binary code */
 
 enum RtOp {
     OP_END = 0,
@@ -42,7 +45,9 @@ enum RtOp {
     OP_DIFF,
     OP_ANGCLIP,     /* a: clip index */
     OP_SKIP_EMPTY,  /* b: jump target when the left operand of the binary op at `cons` is empty (Solids.cpp:1152-1157, :1190-1195) */
-    OP_RETAG        /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
+    OP_RETAG,       /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
+    OP_REGION,      /* a: union region index, tag: consumer of the region's result */
+    OP_RET          /* a: union region index: end of one region child's code */
 };
 
 /* Every instruction that leaves a list names its consumer: tag = 2 * (consumer pc) + side (0 left / only, 1 right). */
@@ -100,6 +105,29 @@ typedef struct RtClip {         /* AngularClip, Solids.h:409-419 */
     int32_t pad_;
 } RtClip;
 
+/* A union region: a maximal connected set of Union/TopUnion nodes with its K non-union children in DFS
+ * order.  The reference evaluates every child and merges along the binary tree (Solids.cpp:1060-1075);
+ * a child whose list is empty is the identity there, so only children whose conservative box the ray
+ * touches need evaluating -- found with a spatial BVH -- PROVIDED the non-empty lists are merged in the
+ * tree's own order.  That order is recovered from lca[]: lca_depth(i, i+1) of adjacent children, with a
+ * sparse table for range minima: of three consecutive non-empty lists a < b < c, (a,b) merge first iff
+ * depth(lca(a,b)) > depth(lca(b,c)). */
+typedef struct RtRegion {
+    int32_t n_children;
+    int32_t child_pc0;      /* first entry in region_child_pc */
+    int32_t bvh_root;       /* index into bvh, -1 = none */
+    int32_t always0, n_always;  /* children with unbounded boxes: always candidates (indices into region_always) */
+    int32_t lca0;           /* sparse table base: level l starts at lca0 + l * n_children */
+    int32_t end_pc;
+    int32_t uid;            /* children produce lists tagged 2*uid */
+} RtRegion;
+
+typedef struct RtBvhNode {
+    double  lo[3], hi[3];
+    int32_t left;           /* >= 0: node index; < 0: ~child index (leaf) */
+    int32_t right;          /* node index (inner nodes only) */
+} RtBvhNode;
+
 typedef struct RtLightDev {
     double  org[3], vA[3], vB[3];
     float   flux[RT_NSPEC];
@@ -118,6 +146,11 @@ typedef struct RtDevScene {
     const RtTexNode     *texnodes;
     const RtClip        *clips;
     const RtLightDev    *lights;
+    const RtRegion      *regions;
+    const RtBvhNode     *bvh;
+    const int32_t       *region_child_pc;
+    const int32_t       *region_always;
+    const int32_t       *region_lca;
     const double        *blue;          /* g_rgvBlueNoise: 1600 x 2 */
     const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */

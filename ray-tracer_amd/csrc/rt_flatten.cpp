@@ -11,6 +11,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdio.h>
+#include <algorithm>
 #include "rt_flatten.h"
 #include "../../include/rt_amd.h"
 
@@ -130,9 +131,10 @@ struct Flattener {
     struct Fwd { double m[9], t[3]; };
     std::vector<Fwd> fwd_stack;     /* forward transforms of enclosing affines (for world boxes) */
     int tex_depth;
+    int region_depth;
 
     Flattener(const RtSceneDesc *dd, RtFlatScene &oo, std::string &e, bool wb)
-        : d(dd), o(oo), err(e), rc(0), with_bounds(wb), next_uid(1), last_affine(-1), tex_depth(0) {}
+        : d(dd), o(oo), err(e), rc(0), with_bounds(wb), next_uid(1), last_affine(-1), tex_depth(0), region_depth(0) {}
 
     bool fail(int code, const std::string &m) { if (!rc) { rc = code; err = m; } return false; }
     const RtNode &N(int i) const { return d->nodes[i]; }
@@ -225,14 +227,106 @@ struct Flattener {
     }
 
     /* emit code for subtree i whose result goes to `tag`; precondition can_hit(i) */
-    void emit(int i, int tag)
+    /* children of the union region rooted at i, in DFS order, with the LCA depth of adjacent children */
+    void collect_region(int i, int depth, std::vector<int> &kids, std::vector<int> &lca)
+    {
+        const RtNode &n = N(i);
+        bool l = can_hit(n.left), r = can_hit(n.right);
+        int sides[2] = { l ? n.left : -1, r ? n.right : -1 };
+        bool first = true;
+        for (int k = 0; k < 2; k++) {
+            int c = sides[k];
+            if (c < 0) continue;
+            if (!first) lca.push_back(depth);       /* gap between the left part's last child and the right part's first */
+            first = false;
+            if (N(c).type == RT_NODE_UNION || N(c).type == RT_NODE_TOPUNION) collect_region(c, depth + 1, kids, lca);
+            else kids.push_back(c);
+        }
+    }
+    int build_bvh(std::vector<int> &idx, int a, int b, const std::vector<Box> &boxes)
+    {
+        RtBvhNode node;
+        memset(&node, 0, sizeof node);
+        Box all;
+        for (int k = a; k < b; k++) all = box_union(all, boxes[idx[k]]);
+        for (int d = 0; d < 3; d++) {
+            double e = 1e-6 * (fabs(all.hi[d] - all.lo[d]) + fabs(all.lo[d]) + fabs(all.hi[d])) + 1e-9;
+            node.lo[d] = all.lo[d] - e; node.hi[d] = all.hi[d] + e;
+        }
+        int me = (int)o.bvh.size();
+        o.bvh.push_back(node);
+        if (b - a == 1) { o.bvh[me].left = ~idx[a]; o.bvh[me].right = -1; return me; }
+        int axis = 0;
+        for (int d = 1; d < 3; d++) if (all.hi[d] - all.lo[d] > all.hi[axis] - all.lo[axis]) axis = d;
+        std::sort(idx.begin() + a, idx.begin() + b, [&](int x, int y) {
+            return boxes[x].lo[axis] + boxes[x].hi[axis] < boxes[y].lo[axis] + boxes[y].hi[axis]; });
+        int mid = (a + b) / 2;
+        int L = build_bvh(idx, a, mid, boxes);
+        int R = build_bvh(idx, mid, b, boxes);
+        o.bvh[me].left = L; o.bvh[me].right = R;
+        return me;
+    }
+    bool emit_region(int i, int tag)
+    {
+        std::vector<int> kids, lca;
+        collect_region(i, 0, kids, lca);
+        int K = (int)kids.size();
+        if (!with_bounds || K < RT_REGION_MIN || region_depth >= RT_MAX_REGION_DEPTH) return false;
+        std::vector<Box> boxes(K);
+        std::vector<int> finite_idx;
+        RtRegion rg;
+        memset(&rg, 0, sizeof rg);
+        rg.n_children = K; rg.uid = next_uid++;
+        rg.always0 = (int)o.region_always.size();
+        bool any = false;
+        for (int k = 0; k < K; k++) {
+            boxes[k] = to_world(local_bound(kids[k]));
+            if (boxes[k].empty) continue;                   /* can never be hit */
+            any = true;
+            if (boxes[k].finite()) finite_idx.push_back(k); else o.region_always.push_back(k);
+        }
+        if (!any) return true;
+        rg.n_always = (int)o.region_always.size() - rg.always0;
+        rg.bvh_root = finite_idx.empty() ? -1 : build_bvh(finite_idx, 0, (int)finite_idx.size(), boxes);
+        /* sparse table of range minima over lca[0..K-2] */
+        rg.lca0 = (int)o.region_lca.size();
+        int levels = 1;
+        while ((1 << levels) < K) levels++;
+        /* level l, entry k = min(lca[k .. k + 2^l - 1]); entries past the end hold INT_MAX */
+        std::vector<int> prev(lca);
+        prev.resize(K, 0x7FFFFFFF);
+        for (int l = 0; l < levels; l++) {
+            o.region_lca.insert(o.region_lca.end(), prev.begin(), prev.end());
+            std::vector<int> next(K, 0x7FFFFFFF);
+            for (int k = 0; k < K; k++) next[k] = (k + (1 << l) < K) ? std::min(prev[k], prev[k + (1 << l)]) : prev[k];
+            prev.swap(next);
+        }
+        rg.child_pc0 = (int)o.region_child_pc.size();
+        o.region_child_pc.resize(o.region_child_pc.size() + K, -1);
+        int ri = (int)o.regions.size();
+        o.regions.push_back(rg);
+        push(OP_REGION, ri, 0, tag);
+        region_depth++;
+        for (int k = 0; k < K; k++) {
+            if (boxes[k].empty) continue;
+            o.region_child_pc[rg.child_pc0 + k] = (int)o.prog.size();
+            emit(kids[k], 2 * rg.uid, true);
+            push(OP_RET, ri, 0, 0);
+        }
+        region_depth--;
+        o.regions[ri].end_pc = (int)o.prog.size();
+        o.culled_subtrees += K;
+        return true;
+    }
+
+    void emit(int i, int tag, bool no_root_bound = false)
     {
         if (rc) return;
         const RtNode &n = N(i);
         int bound_pc = -1;
         bool is_leaf = (n.type >= RT_NODE_QUADRIC && n.type <= RT_NODE_TORUS) || n.type == RT_NODE_CONEHYPERCYL;
         /* a box in front of: every leaf, every affine, every binary node (not in front of pure wrappers: same box as their child) */
-        bool boxed = with_bounds && (is_leaf || n.type == RT_NODE_AFFINE || (n.type >= RT_NODE_UNION && n.type <= RT_NODE_DIFFERENCE));
+        bool boxed = with_bounds && !no_root_bound && (is_leaf || n.type == RT_NODE_AFFINE || (n.type >= RT_NODE_UNION && n.type <= RT_NODE_DIFFERENCE));
         if (boxed) {
             Box b = to_world(local_bound(i));
             if (b.empty) return;                       /* no points at all: statically empty */
@@ -265,6 +359,7 @@ struct Flattener {
         }
         case RT_NODE_UNION: case RT_NODE_TOPUNION: {
             bool l = can_hit(n.left), r = can_hit(n.right);
+            if (l && r && emit_region(i, tag)) break;
             if (l && r) {
                 int uid = next_uid++;
                 emit(n.left, 2 * uid);

@@ -15,6 +15,9 @@ struct RtFlatScene {
     std::vector<RtTexNode>     texnodes;
     std::vector<RtClip>        clips;
     std::vector<RtLightDev>    lights;
+    std::vector<RtRegion>      regions;
+    std::vector<RtBvhNode>     bvh;
+    std::vector<int32_t>       region_child_pc, region_always, region_lca;
     int  irregular_leaves;      /* leaves whose recorded affine is not their innermost enclosing affine */
     int  culled_subtrees;       /* OP_BOUND instructions emitted */
     RtFlatScene() : irregular_leaves(0), culled_subtrees(0) {}

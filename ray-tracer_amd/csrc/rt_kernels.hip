@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, 
         int start;
         int count = intersect_scene(S, ray, RT_INFINITY, A, start);
         if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
-        atomicAdd(&P.counters[FR_DEPTH(flags) == 0 ? CTR_PRIMARY : CTR_SECONDARY], 1);
         /* Shade.cpp:424-432: regularise into (0, t, ...) */
         int i = 0, pm = 0;
         if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
@@ -264,7 +263,6 @@ __global__ void __launch_bounds__(256) k_shadow(const RtDevScene *Sp, RtPipe P, 
     int start;
     int count = intersect_scene(S, ray, 1.0, A, start);
     if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
-    atomicAdd(&P.counters[CTR_SHADOWRAYS], 1);
     int i = 0, pm = 0;
     if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
     double t = 0.0;
