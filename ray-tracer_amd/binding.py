@@ -6,7 +6,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_RT = os.path.join(HERE, "librt_amd.so")
+LIB_RT = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")   # RT_AMD_LIB: A/B builds of the same library
 LIB_FRONTEND = os.path.join(HERE, "librt_frontend.so")
 TABLES = os.path.join(HERE, "data", "tables.bin")
 NSPEC = 10

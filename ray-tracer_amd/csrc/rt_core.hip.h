@@ -206,7 +206,17 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     int      nlist;
     int      top;           /* first free hit slot */
     int      overflow;
+#ifdef RT_PHASE_PROF
+    int      prof[4];       /* cycles: [1] BVH candidate search, [2] primitive tests, [3] whole intersect */
+#endif
 };
+#ifdef RT_PHASE_PROF
+#define PROF_BEGIN(v)      long long v = clock64()
+#define PROF_END(A, k, v)  (A).prof[k] += (int)(clock64() - v)
+#else
+#define PROF_BEGIN(v)
+#define PROF_END(A, k, v)
+#endif
 
 /* HitWork (Solids.h:47-58): up to 4 roots; slot [-1] is addressable */
 struct Work {
@@ -321,23 +331,35 @@ RT_DEV int extent_test(const double *lo, const double *hi, const DRay &ray)
     return 1;
 }
 
-/* this build's culling test: does the world ray, t in [0, tmax], touch the (padded, conservative) box? */
-RT_DEV bool cull_box_hit(const RtBox &b, const DRay &ray, double tmax)
+/* this build's culling test: does the world ray, t in [0, tmax], touch the (padded, conservative) box?
+   Not part of the reference's arithmetic: any conservative test gives the same hit lists.  The reciprocal
+   direction is formed once per ray. */
+struct CullRay { double o[3], inv[3], tmax; int zmask; };
+RT_DEV CullRay cull_ray(const DRay &r, double tmax)
 {
-    double t0 = 0.0, t1 = tmax;
-    const double o[3] = { ray.org.x, ray.org.y, ray.org.z }, dd[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+    CullRay c;
+    c.o[0] = r.org.x; c.o[1] = r.org.y; c.o[2] = r.org.z;
+    const double d[3] = { r.dir.x, r.dir.y, r.dir.z };
+    c.zmask = 0;
     for (int i = 0; i < 3; i++) {
-        if (dd[i] != 0.0) {
-            double inv = 1.0 / dd[i];
-            double ta = (b.lo[i] - o[i]) * inv, tb = (b.hi[i] - o[i]) * inv;
-            double tn = fmin(ta, tb), tf = fmax(ta, tb);
-            /* two roundings (reciprocal, product): widen by a few ulps so the test stays conservative */
-            tn -= fabs(tn) * 4e-16; tf += fabs(tf) * 4e-16;
-            t0 = fmax(t0, tn); t1 = fmin(t1, tf);
-        } else if (o[i] < b.lo[i] || o[i] > b.hi[i])
+        if (d[i] != 0.0) c.inv[i] = 1.0 / d[i];
+        else { c.inv[i] = 0.0; c.zmask |= 1 << i; }
+    }
+    c.tmax = tmax;
+    return c;
+}
+RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
+{
+    double t0 = 0.0, t1 = c.tmax;
+    for (int i = 0; i < 3; i++) {
+        if (!(c.zmask & (1 << i))) {
+            double ta = (lo[i] - c.o[i]) * c.inv[i], tb = (hi[i] - c.o[i]) * c.inv[i];
+            t0 = fmax(t0, fmin(ta, tb)); t1 = fmin(t1, fmax(ta, tb));
+        } else if (c.o[i] < lo[i] || c.o[i] > hi[i])
             return false;
     }
-    return t0 <= t1;
+    /* three roundings per bound (reciprocal, difference, product): widen by a few ulps so the test stays conservative */
+    return t0 - t0 * 8e-16 <= t1 + fabs(t1) * 8e-16;
 }
 
 /* ================================================================== primitives */
@@ -384,7 +406,7 @@ __device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena
     hit_list(w, A, tag, prim, p.leaf_affine);
 }
 
-__device__ void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
+RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
 {
     const double rm = tp.p[0];
     const double lo[3] = { -1.0 - rm, -1.0 - rm, -rm }, hi[3] = { 1.0 + rm, 1.0 + rm, rm };
@@ -503,23 +525,70 @@ RT_DEV int region_gap(const RtDevScene &S, const RtRegion &rg, int a, int b)
     return x < y ? x : y;
 }
 
+/* workgroup-shared staging: the top of the scene's BVH and the per-lane traversal stacks (blockDim.x == 256) */
+struct SceneLds {
+    double   bvh[RT_LDS_BVH_NODES * (sizeof(RtBvhNode) / 8)];
+    uint16_t stack[RT_BVH_STACK][256];
+};
+/* every thread of the workgroup must call this before intersect_scene */
+RT_DEV void scene_lds_load(const RtDevScene &S, SceneLds &L)
+{
+    int n = S.n_bvh < RT_LDS_BVH_NODES ? S.n_bvh : RT_LDS_BVH_NODES;
+    int words = n * (int)(sizeof(RtBvhNode) / 8);
+    const double *src = (const double *)S.bvh;
+    for (int k = threadIdx.x; k < words; k += blockDim.x) L.bvh[k] = src[k];
+    __syncthreads();
+}
+
+/* one 4-wide node: test the four child boxes together */
+RT_DEV unsigned bvh4_test(const double *nb, const CullRay &c, int32_t child[4])
+{
+    double t0[4], t1[4];
+    unsigned alive = 0xF;
+    for (int k = 0; k < 4; k++) { t0[k] = 0.0; t1[k] = c.tmax; }
+    for (int d = 0; d < 3; d++) {
+        const double *lo = nb + 4 * d, *hi = nb + 12 + 4 * d;
+        if (!(c.zmask & (1 << d))) {
+            for (int k = 0; k < 4; k++) {
+                double ta = (lo[k] - c.o[d]) * c.inv[d], tb = (hi[k] - c.o[d]) * c.inv[d];
+                t0[k] = fmax(t0[k], fmin(ta, tb)); t1[k] = fmin(t1[k], fmax(ta, tb));
+            }
+        } else {
+            for (int k = 0; k < 4; k++) if (c.o[d] < lo[k] || c.o[d] > hi[k]) alive &= ~(1u << k);
+        }
+    }
+    const int32_t *ch = (const int32_t *)(nb + 24);
+    unsigned hit = 0;
+    for (int k = 0; k < 4; k++) {
+        child[k] = ch[k];
+        if ((alive & (1u << k)) && child[k] != RT_BVH_EMPTY && t0[k] - t0[k] * 8e-16 <= t1[k] + fabs(t1[k]) * 8e-16) hit |= 1u << k;
+    }
+    return hit;
+}
+
 /* candidates of a union region: children with unbounded boxes plus those whose box the ray touches,
    ascending (= the reference's evaluation order) */
-__device__ int region_candidates(const RtDevScene &S, const RtRegion &rg, const DRay &wray, double tmax, uint16_t *cand, int &overflow)
+__device__ int region_candidates(const RtDevScene &S, SceneLds &L, const RtRegion &rg, const CullRay &cr, uint16_t *cand, int &overflow)
 {
     int n = 0;
     for (int k = 0; k < rg.n_always; k++) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)S.region_always[rg.always0 + k]; else overflow = 1; }
     if (rg.bvh_root >= 0) {
-        int stack[48], sp = 0;
-        stack[sp++] = rg.bvh_root;
-        while (sp > 0) {
-            const RtBvhNode &nd = S.bvh[stack[--sp]];
-            RtBox b;
-            for (int d = 0; d < 3; d++) { b.lo[d] = nd.lo[d]; b.hi[d] = nd.hi[d]; }
-            if (!cull_box_hit(b, wray, tmax)) continue;
-            if (nd.left < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~nd.left); else overflow = 1; }
-            else if (sp + 2 <= 48) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
-            else overflow = 1;
+        const int lane = threadIdx.x;
+        int sp = 0;
+        int node = rg.bvh_root;
+        for (;;) {
+            int32_t child[4];
+            unsigned hit;
+            if (node < RT_LDS_BVH_NODES) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
+            else hit = bvh4_test((const double *)(S.bvh + node), cr, child);
+            for (int k = 3; k >= 0; k--) {
+                if (!(hit & (1u << k))) continue;
+                if (child[k] < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~child[k]); else overflow = 1; }
+                else if (sp < RT_BVH_STACK) L.stack[sp++][lane] = (uint16_t)child[k];
+                else overflow = 1;
+            }
+            if (sp == 0) break;
+            node = L.stack[--sp][lane];
         }
     }
     for (int i = 1; i < n; i++) {           /* insertion sort: n is small */
@@ -531,14 +600,19 @@ __device__ int region_candidates(const RtDevScene &S, const RtRegion &rg, const 
     return n;
 }
 
-__device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tmax, Arena &A, int &start)
+__device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
     RegionFrame rf[RT_MAX_REGION_DEPTH];
     int nrf = 0;
     int depth = 0;
     rs[0] = wray;
+    const CullRay cr = cull_ray(wray, tmax);
     A.nlist = 0; A.top = 0; A.overflow = 0;
+#ifdef RT_PHASE_PROF
+    A.prof[0] = A.prof[1] = A.prof[2] = A.prof[3] = 0;
+#endif
+    PROF_BEGIN(t_all);
     int pc = 0;
     for (;;) {
         const RtInstr in = S.prog[pc];
@@ -547,7 +621,7 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
         case OP_END:
             goto done;
         case OP_BOUND:
-            if (!cull_box_hit(S.boxes[in.a], wray, tmax)) pc = in.b;
+            if (!cull_box_hit(S.boxes[in.a].lo, S.boxes[in.a].hi, cr)) pc = in.b;
             break;
         case OP_REFBOX:
             if (!extent_test(S.boxes[in.a].lo, S.boxes[in.a].hi, rs[depth])) pc = in.b;
@@ -564,10 +638,10 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
         case OP_POP_AFFINE:
             depth--;
             break;
-        case OP_QUADRIC: quadric_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
-        case OP_POLY:    poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, rs[depth], A, in.tag); break;
-        case OP_SLAB:    slab_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
-        case OP_TORUS:   torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); break;
+        case OP_QUADRIC: { PROF_BEGIN(tp); quadric_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_POLY:    { PROF_BEGIN(tp); poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_SLAB:    { PROF_BEGIN(tp); slab_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_TORUS:   { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
@@ -625,7 +699,9 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
             if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow = 1; pc = rg.end_pc; break; }
             RegionFrame &f = rf[nrf];
             int ov = 0;
-            f.ncand = region_candidates(S, rg, wray, tmax, f.cand, ov);
+            PROF_BEGIN(tb);
+            f.ncand = region_candidates(S, L, rg, cr, f.cand, ov);
+            PROF_END(A, 1, tb);
             if (ov) A.overflow = 1;
             if (f.ncand == 0) { pc = rg.end_pc; break; }
             f.region = in.a; f.pos = 0; f.base_lists = A.nlist; f.nl_before = A.nlist; f.out_tag = in.tag;
@@ -633,7 +709,57 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
             pc = S.region_child_pc[rg.child_pc0 + f.cand[0]];
             break;
         }
-        case OP_RET: {
+        case OP_CHAIN: {
+            const RtChain &ch = S.chains[in.a];
+            if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b) goto region_ret; break; }
+            DRay r = rs[depth];
+            for (int k = 0; k < ch.n_affine; k++) {                 /* AffineSolid::Intersect, Solids.cpp:899-913 */
+                const RtAffine &a = S.affines[ch.affine[k]];
+                DRay nr;
+                nr.dir = mat_vec(a.minv, r.dir);
+                nr.org = mat_vec(a.minv, r.org - d3(a.tr[0], a.tr[1], a.tr[2]));
+                r = nr;
+            }
+            const int before = A.nlist;
+            {
+                PROF_BEGIN(tp);
+                switch (ch.prim_op) {
+                case OP_QUADRIC: quadric_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
+                case OP_POLY:    poly_hits(S.prims[ch.prim], (uint16_t)ch.prim, S.planes, r, A, in.tag); break;
+                case OP_SLAB:    slab_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
+                default:         torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
+                }
+                PROF_END(A, 2, tp);
+            }
+            if (A.nlist > before) {
+                const int li = A.nlist - 1, s0 = A.l_start[li], c = A.l_count[li];
+                for (int w = 0; w < ch.n_wrap; w++) {
+                    const int wi = ch.wrap[w];
+                    if (wi >= 0) {                                  /* Material::Intersect, Solids.cpp:1466-1487 */
+                        const int mtex = S.mats[wi].tex;
+                        for (int i = 0; i < c; i++) {
+                            HitRec &h = A.h[s0 + i];
+                            if (S.mats[h.mat].density > 0.0) {
+                                h.mat = (uint16_t)wi;
+                                if (mtex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)mtex;
+                            }
+                        }
+                    } else {                                        /* Surface::Intersect, Solids.cpp:1498-1519 */
+                        const int si = ~wi, stex = S.surfs[si].tex;
+                        for (int i = 0; i < c; i++) {
+                            HitRec &h = A.h[s0 + i];
+                            if (h.t == 0.0) continue;
+                            h.surf = (uint16_t)si;
+                            if (stex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)stex;
+                        }
+                    }
+                }
+            }
+            if (in.b) goto region_ret;
+            break;
+        }
+        case OP_RET:
+        region_ret: {
             /* one region child done: fold the non-empty lists in the union tree's own order */
             RegionFrame &f = rf[nrf - 1];
             const RtRegion &rg = S.regions[f.region];
@@ -683,6 +809,7 @@ __device__ int intersect_scene(const RtDevScene &S, const DRay &wray, double tma
         }
     }
 done:
+    PROF_END(A, 3, t_all);
     if (A.nlist > 0 && A.l_tag[A.nlist - 1] == 0) { start = A.l_start[A.nlist - 1]; return A.l_count[A.nlist - 1]; }
     start = 0;
     return 0;
@@ -797,7 +924,7 @@ __device__ const double kDodeca[20][3] = {
 #undef P2_
 };
 
-__device__ void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux)        /* TextureMaps.cpp:209-369 */
+RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux)        /* TextureMaps.cpp:209-369 */
 {
     float q[3], g[3];
     switch (tex) {
@@ -950,7 +1077,7 @@ RT_DEV Cx cdiv(Cx a, Cx c)          /* Complex.h:21-33 */
     return cx((a.im * q + a.re) / den, (a.im - a.re * q) / den);
 }
 /* FresnelLaw_Complex + Fresnel_Spectral, Shade.cpp:117-153 */
-__device__ Spec fresnel_spectral(double fNE, double n1r, const float *nn, const float *kk)
+RT_DEVN Spec fresnel_spectral(double fNE, double n1r, const float *nn, const float *kk)
 {
     Spec s;
     double F = 0.0;
@@ -1031,7 +1158,7 @@ RT_DEV Spec ray_reflectance(int luster, const Spec &color, double F)
 }
 
 /* ColoredGlass / Foggy, TextureMaps.cpp:13-57 */
-__device__ void propagate(int id, const D3 &p0, const D3 &p1, const float *color, Spec &tr, Spec &ster)
+RT_DEVN void propagate(int id, const D3 &p0, const D3 &p1, const float *color, Spec &tr, Spec &ster)
 {
     if (id == RT_PROP_FOGGY) {
         double t = norm(p1 - p0);

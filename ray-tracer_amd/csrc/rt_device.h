@@ -47,7 +47,8 @@ enum RtOp {
     OP_SKIP_EMPTY,  /* b: jump target when the left operand of the binary op at `cons` is empty (Solids.cpp:1152-1157, :1190-1195) */
     OP_RETAG,       /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
     OP_REGION,      /* a: union region index, tag: consumer of the region's result */
-    OP_RET          /* a: union region index: end of one region child's code */
+    OP_RET,         /* a: union region index: end of one region child's code */
+    OP_CHAIN        /* a: chain index: [box] affine* primitive (material|surface)* in one step; b != 0: followed by the region's OP_RET */
 };
 
 /* Every instruction that leaves a list names its consumer: tag = 2 * (consumer pc) + side (0 left / only, 1 right). */
@@ -122,11 +123,29 @@ typedef struct RtRegion {
     int32_t uid;            /* children produce lists tagged 2*uid */
 } RtRegion;
 
+/* 4-wide node: the four child boxes are tested together (independent arithmetic hides latency at one or two
+   waves per SIMD), the tree is half as deep as a binary one, and the first RT_LDS_BVH_NODES nodes of a scene
+   are staged in LDS by every workgroup. */
+#define RT_BVH_EMPTY     ((int32_t)0x80000000)
+#define RT_LDS_BVH_NODES 192        /* 192 * 208 B = 39 KB of LDS */
+#define RT_BVH_STACK     28         /* pending nodes per ray (LDS, 2 B each) */
 typedef struct RtBvhNode {
-    double  lo[3], hi[3];
-    int32_t left;           /* >= 0: node index; < 0: ~child index (leaf) */
-    int32_t right;          /* node index (inner nodes only) */
+    double  lo[3][4], hi[3][4];
+    int32_t child[4];       /* >= 0: node index; < 0: ~(region child index) (leaf); RT_BVH_EMPTY: unused slot */
 } RtBvhNode;
+
+/* A chain: single-child wrappers around one primitive, the commonest shape of a scene object
+   (Translate(Scale(Material(Surface(Sphere))))).  Evaluated by one OP_CHAIN instead of
+   [BOUND] PUSH_AFFINE.. primitive MATERIAL/SURFACE.. POP_AFFINE..: same operations in the same order. */
+#define RT_CHAIN_AFFINES 3
+#define RT_CHAIN_WRAPS   6
+typedef struct RtChain {
+    int32_t prim_op, prim;
+    int32_t box;            /* the chain's conservative world box, -1 = unbounded */
+    int32_t test_box;       /* 0 when the caller (a region's BVH leaf) has already tested that box */
+    int32_t n_affine, affine[RT_CHAIN_AFFINES];     /* outermost first */
+    int32_t n_wrap, wrap[RT_CHAIN_WRAPS];           /* innermost first; >= 0: material index, < 0: ~surface index */
+} RtChain;
 
 typedef struct RtLightDev {
     double  org[3], vA[3], vB[3];
@@ -148,13 +167,14 @@ typedef struct RtDevScene {
     const RtLightDev    *lights;
     const RtRegion      *regions;
     const RtBvhNode     *bvh;
+    const RtChain       *chains;
     const int32_t       *region_child_pc;
     const int32_t       *region_always;
     const int32_t       *region_lca;
     const double        *blue;          /* g_rgvBlueNoise: 1600 x 2 */
     const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
-    int32_t n_prog, n_lights, has_ambient, sampler, venera, pad_;
+    int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
     float   ambient[RT_NSPEC];
     float   spec2rgb[RT_NSPEC][3];
     float   chan[3][RT_NSPEC];

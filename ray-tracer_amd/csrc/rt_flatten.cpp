@@ -243,28 +243,58 @@ struct Flattener {
             else kids.push_back(c);
         }
     }
-    int build_bvh(std::vector<int> &idx, int a, int b, const std::vector<Box> &boxes)
+    /* sort idx[a,b) along the longest axis of its bound and return the median position */
+    int split_range(std::vector<int> &idx, int a, int b, const std::vector<Box> &boxes)
     {
-        RtBvhNode node;
-        memset(&node, 0, sizeof node);
         Box all;
         for (int k = a; k < b; k++) all = box_union(all, boxes[idx[k]]);
-        for (int d = 0; d < 3; d++) {
-            double e = 1e-6 * (fabs(all.hi[d] - all.lo[d]) + fabs(all.lo[d]) + fabs(all.hi[d])) + 1e-9;
-            node.lo[d] = all.lo[d] - e; node.hi[d] = all.hi[d] + e;
-        }
-        int me = (int)o.bvh.size();
-        o.bvh.push_back(node);
-        if (b - a == 1) { o.bvh[me].left = ~idx[a]; o.bvh[me].right = -1; return me; }
         int axis = 0;
         for (int d = 1; d < 3; d++) if (all.hi[d] - all.lo[d] > all.hi[axis] - all.lo[axis]) axis = d;
         std::sort(idx.begin() + a, idx.begin() + b, [&](int x, int y) {
             return boxes[x].lo[axis] + boxes[x].hi[axis] < boxes[y].lo[axis] + boxes[y].hi[axis]; });
-        int mid = (a + b) / 2;
-        int L = build_bvh(idx, a, mid, boxes);
-        int R = build_bvh(idx, mid, b, boxes);
-        o.bvh[me].left = L; o.bvh[me].right = R;
-        return me;
+        return (a + b) / 2;
+    }
+    /* 4-wide BVH over idx[a,b) (b - a >= 1): two levels of median splits per node; nodes are numbered breadth
+       first so that the top of the tree is what lands in LDS */
+    int build_bvh(std::vector<int> &idx, int a0, int b0, const std::vector<Box> &boxes)
+    {
+        struct Job { int node, a, b; };
+        std::vector<Job> queue;
+        int root = (int)o.bvh.size();
+        o.bvh.push_back(RtBvhNode());
+        queue.push_back(Job{ root, a0, b0 });
+        for (size_t q = 0; q < queue.size(); q++) {
+            Job j = queue[q];
+            int cuts[5], nc = 0;
+            if (j.b - j.a <= 4) { for (int k = j.a; k <= j.b; k++) cuts[nc++] = k; }
+            else {
+                int m = split_range(idx, j.a, j.b, boxes);
+                int l = split_range(idx, j.a, m, boxes), r = split_range(idx, m, j.b, boxes);
+                cuts[0] = j.a; cuts[1] = l; cuts[2] = m; cuts[3] = r; cuts[4] = j.b; nc = 5;
+            }
+            RtBvhNode node;
+            memset(&node, 0, sizeof node);
+            for (int c = 0; c < 4; c++) {
+                node.child[c] = RT_BVH_EMPTY;
+                for (int d = 0; d < 3; d++) { node.lo[d][c] = 0.0; node.hi[d][c] = 0.0; }
+                if (c + 1 >= nc) continue;
+                int a = cuts[c], b = cuts[c + 1];
+                Box all;
+                for (int k = a; k < b; k++) all = box_union(all, boxes[idx[k]]);
+                for (int d = 0; d < 3; d++) {
+                    double e = 1e-6 * (fabs(all.hi[d] - all.lo[d]) + fabs(all.lo[d]) + fabs(all.hi[d])) + 1e-9;
+                    node.lo[d][c] = all.lo[d] - e; node.hi[d][c] = all.hi[d] + e;
+                }
+                if (b - a == 1) node.child[c] = ~idx[a];
+                else {
+                    node.child[c] = (int)o.bvh.size();
+                    o.bvh.push_back(RtBvhNode());
+                    queue.push_back(Job{ node.child[c], a, b });
+                }
+            }
+            o.bvh[j.node] = node;
+        }
+        return root;
     }
     bool emit_region(int i, int tag)
     {
@@ -310,8 +340,10 @@ struct Flattener {
         for (int k = 0; k < K; k++) {
             if (boxes[k].empty) continue;
             o.region_child_pc[rg.child_pc0 + k] = (int)o.prog.size();
+            size_t before = o.prog.size();
             emit(kids[k], 2 * rg.uid, true);
-            push(OP_RET, ri, 0, 0);
+            if (o.prog.size() == before + 1 && o.prog.back().op == OP_CHAIN) o.prog.back().b = 1;    /* chain + return in one step */
+            else push(OP_RET, ri, 0, 0);
         }
         region_depth--;
         o.regions[ri].end_pc = (int)o.prog.size();
@@ -319,9 +351,92 @@ struct Flattener {
         return true;
     }
 
+    /* [affine | material | surface]* primitive  ->  one OP_CHAIN.  Table entries are created in the same order as
+       the general code below would create them (pre-order), so indices, static affine tracking (Q12) and texture
+       call-out levels are unchanged. */
+    bool try_chain(int i, int tag, bool no_root_bound)
+    {
+        std::vector<int> path;
+        int c = i, na = 0, nw = 0;
+        for (;;) {
+            if (c < 0) return false;
+            int t = N(c).type;
+            if (t == RT_NODE_AFFINE) na++;
+            else if (t == RT_NODE_MATERIAL || t == RT_NODE_SURFACE) nw++;
+            else break;
+            path.push_back(c);
+            c = N(c).left;
+        }
+        int lt = N(c).type, op;
+        if (lt == RT_NODE_QUADRIC || lt == RT_NODE_CONEHYPERCYL) op = OP_QUADRIC;
+        else if (lt == RT_NODE_POLYHEDRON) op = OP_POLY;
+        else if (lt == RT_NODE_SLAB) op = OP_SLAB;
+        else if (lt == RT_NODE_TORUS) op = OP_TORUS;
+        else return false;
+        if (na > RT_CHAIN_AFFINES || nw > RT_CHAIN_WRAPS) return false;
+        if ((int)affine_stack.size() + na > RT_MAX_AFFINE_DEPTH) return false;      /* let the general code report it */
+        RtChain ch;
+        memset(&ch, 0, sizeof ch);
+        ch.box = -1;
+        if (with_bounds) {
+            Box b = to_world(local_bound(i));
+            if (b.empty && !no_root_bound) return true;         /* statically empty: nothing to emit */
+            if (!b.empty && b.finite()) { ch.box = add_box(b, true); ch.test_box = no_root_bound ? 0 : 1; if (ch.test_box) o.culled_subtrees++; }
+        }
+        int wraps[RT_CHAIN_WRAPS], tex_added = 0;
+        for (size_t k = 0; k < path.size(); k++) {
+            int j = path[k];
+            const RtNode &n = N(j);
+            const double *p = D(j);
+            if (n.type == RT_NODE_AFFINE) {
+                RtAffine a;
+                memcpy(a.minv, p + 9, sizeof a.minv);
+                memcpy(a.tr, p + 18, sizeof a.tr);
+                a.tree_parent = affine_stack.empty() ? -1 : affine_stack.back();
+                a.link = (n.link >= 0 && n.link < (int)node_affine.size()) ? node_affine[n.link] : -1;
+                int ai = (int)o.affines.size();
+                o.affines.push_back(a);
+                node_affine[j] = ai;
+                Fwd f; memcpy(f.m, p, sizeof f.m); memcpy(f.t, p + 18, sizeof f.t);
+                affine_stack.push_back(ai); fwd_stack.push_back(f);
+                last_affine = ai;
+                ch.affine[ch.n_affine++] = ai;
+            } else if (n.type == RT_NODE_MATERIAL) {
+                if (n.i0 < RT_MAT_NOSHADE || n.i0 > RT_MAT_TITANIUM) return fail(RT_ERR_INVALID, "material luster out of range"), true;
+                if (n.i2 < 0 || n.i2 >= RT_PROP__COUNT) return fail(RT_ERR_UNSUPPORTED, "unknown propagator"), true;
+                RtMaterialDev m;
+                memset(&m, 0, sizeof m);
+                m.density = p[0]; m.refr = p[1];
+                for (int q = 0; q < RT_NSPEC; q++) m.color[q] = (float)p[2 + q];
+                m.luster = n.i0; m.prop = n.i2; m.id = n.id;
+                if (n.i1) { tex_added++; if (++tex_depth > RT_MAX_TEX) return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"), true; }
+                m.tex = tex_node(n.i1, n.link);
+                wraps[ch.n_wrap++] = (int)o.mats.size();
+                o.mats.push_back(m);
+            } else {
+                RtSurfaceDev sf;
+                memset(&sf, 0, sizeof sf);
+                sf.roughness = n.i0; sf.id = n.id;
+                if (n.i1) { tex_added++; if (++tex_depth > RT_MAX_TEX) return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"), true; }
+                sf.tex = tex_node(n.i1, n.link);
+                wraps[ch.n_wrap++] = ~(int)o.surfs.size();
+                o.surfs.push_back(sf);
+            }
+        }
+        ch.prim_op = op;
+        ch.prim = leaf(op, c);
+        for (int k = 0; k < ch.n_wrap; k++) ch.wrap[k] = wraps[ch.n_wrap - 1 - k];     /* innermost first */
+        for (int k = 0; k < ch.n_affine; k++) { affine_stack.pop_back(); fwd_stack.pop_back(); }
+        tex_depth -= tex_added;
+        o.chains.push_back(ch);
+        push(OP_CHAIN, (int)o.chains.size() - 1, 0, tag);
+        return true;
+    }
+
     void emit(int i, int tag, bool no_root_bound = false)
     {
         if (rc) return;
+        if (try_chain(i, tag, no_root_bound)) return;
         const RtNode &n = N(i);
         int bound_pc = -1;
         bool is_leaf = (n.type >= RT_NODE_QUADRIC && n.type <= RT_NODE_TORUS) || n.type == RT_NODE_CONEHYPERCYL;

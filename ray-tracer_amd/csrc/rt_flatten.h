@@ -17,6 +17,7 @@ struct RtFlatScene {
     std::vector<RtLightDev>    lights;
     std::vector<RtRegion>      regions;
     std::vector<RtBvhNode>     bvh;
+    std::vector<RtChain>       chains;
     std::vector<int32_t>       region_child_pc, region_always, region_lca;
     int  irregular_leaves;      /* leaves whose recorded affine is not their innermost enclosing affine */
     int  culled_subtrees;       /* OP_BOUND instructions emitted */

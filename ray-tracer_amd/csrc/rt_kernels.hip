@@ -72,22 +72,22 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
     aux[5] = aux[3];
 }
 
-__global__ void k_probe_samples(const RtDevScene *Sp, RtSampleGrid g, int64_t first, int64_t n, double *out8, double *out_xy)
+__global__ void k_probe_samples(const RtDevScene Sv, RtSampleGrid g, int64_t first, int64_t n, double *out8, double *out_xy)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double pos[2], v[2], aux[6];
-    sample_at(*Sp, g, first + k, pos, v, aux);
+    sample_at(Sv, g, first + k, pos, v, aux);
     out8[8 * k] = v[0]; out8[8 * k + 1] = v[1];
     for (int i = 0; i < 6; i++) out8[8 * k + 2 + i] = aux[i];
     out_xy[2 * k] = pos[0]; out_xy[2 * k + 1] = pos[1];
 }
 
-__global__ void k_probe_camera(const RtDevScene *Sp, int n, const double *v2, const double *aux6, double *org, double *dir)
+__global__ void k_probe_camera(const RtDevScene Sv, int n, const double *v2, const double *aux6, double *org, double *dir)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
     double uC = aux6 ? aux6[6 * k] : S.aux_init[0], vC = aux6 ? aux6[6 * k + 1] : S.aux_init[1];
     DRay r = camera_emit(S.cam, v2[2 * k], v2[2 * k + 1], uC, vC);
     org[3 * k] = r.org.x; org[3 * k + 1] = r.org.y; org[3 * k + 2] = r.org.z;
@@ -95,11 +95,11 @@ __global__ void k_probe_camera(const RtDevScene *Sp, int n, const double *v2, co
 }
 
 /* root frames for samples [first, first+n) of the grid; or for user rays (probe) when rays != 0 */
-__global__ void __launch_bounds__(256) k_generate(const RtDevScene *Sp, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
+__global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
     double aux[6];
     DRay r;
     if (rays_org) {
@@ -119,12 +119,21 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene *Sp, RtSample
     P.f_flags[k] = 0;
 }
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 1     /* minimum waves per SIMD the tracing kernels are compiled for */
+#endif
 /* ------------------------------------------------------------------ k_visual */
-__global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, int f0, int f1)
+__global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
 {
     int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = f < f1;
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
+    __shared__ SceneLds lds;
+    scene_lds_load(S, lds);
+#ifdef RT_PHASE_PROF
+    long long prof_t0 = clock64();
+    int prof_v[4] = { 0, 0, 0, 0 };
+#endif
     int n_shadow = 0;
     unsigned mask = 0;
     DRay sdir[1];
@@ -141,8 +150,11 @@ __global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, 
         for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
         Arena A;
         int start;
-        int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+        int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
         if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+#ifdef RT_PHASE_PROF
+        for (int q = 1; q < 4; q++) prof_v[q] = A.prof[q];
+#endif
         /* Shade.cpp:424-432: regularise into (0, t, ...) */
         int i = 0, pm = 0;
         if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
@@ -223,6 +235,14 @@ __global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, 
     }
     /* append this lane's shadow rays to the queue: one atomic per wave */
     int base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
+#ifdef RT_PHASE_PROF
+    prof_v[0] = (int)(clock64() - prof_t0);
+    for (int q = 0; q < 4; q++) {           /* per-wave maxima, in units of 16 cycles */
+        int v = prof_v[q];
+        for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PRIMARY + q], v >> 4);
+    }
+#endif
     if (!live) return;
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
     P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
@@ -245,11 +265,13 @@ __global__ void __launch_bounds__(256) k_visual(const RtDevScene *Sp, RtPipe P, 
 }
 
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359 */
-__global__ void __launch_bounds__(256) k_shadow(const RtDevScene *Sp, RtPipe P, int n)
+__global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_shadow(const RtDevScene Sv, RtPipe P, int n)
 {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const RtDevScene &S = Sv;
+    __shared__ SceneLds lds;
+    scene_lds_load(S, lds);
     if (s >= n) return;
-    const RtDevScene &S = *Sp;
     DRay ray;
     ray.org = d3_fetch(P.s_ray, P.scap, 0, s);
     ray.dir = d3_fetch(P.s_ray, P.scap, 3, s);
@@ -261,7 +283,7 @@ __global__ void __launch_bounds__(256) k_shadow(const RtDevScene *Sp, RtPipe P, 
     Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
     Arena A;
     int start;
-    int count = intersect_scene(S, ray, 1.0, A, start);
+    int count = intersect_scene(S, lds, ray, 1.0, A, start);
     if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
     int i = 0, pm = 0;
     if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
@@ -303,11 +325,11 @@ __global__ void __launch_bounds__(256) k_shadow(const RtDevScene *Sp, RtPipe P, 
 }
 
 /* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
-__global__ void __launch_bounds__(256) k_shade(const RtDevScene *Sp, RtPipe P, int f0, int f1)
+__global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1)
 {
     int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = f < f1;
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
     int nchild = 0, flags = 0;
     bool want_refl = false, want_refr = false;
     D3 Ppt = d3(0, 0, 0), dir_refl = d3(0, 0, 0), dir_refr = d3(0, 0, 0);
@@ -379,11 +401,11 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene *Sp, RtPipe P, i
 }
 
 /* ------------------------------------------------------------------ k_resolve */
-__global__ void __launch_bounds__(256) k_resolve(const RtDevScene *Sp, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+__global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
 {
     int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= f1) return;
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
     int flags = P.f_flags[f];
     Spec R = spec_fetch(P.f_R, P.fcap, f);
     if (flags & FR_BOUNDARY) {
@@ -416,13 +438,15 @@ __global__ void __launch_bounds__(256) k_resolve(const RtDevScene *Sp, RtPipe P,
 }
 
 /* ------------------------------------------------------------------ probe: raw hit lists */
-__global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, int n, const double *org, const double *dir, const double *aux6,
+__global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, int n, const double *org, const double *dir, const double *aux6,
                                                          int max_hits, int transform, int *out_count, double *out_t, double *out_n,
                                                          int *out_leaf, int *out_mat, int *out_surf, int *overflow)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const RtDevScene &S = Sv;
+    __shared__ SceneLds lds;
+    scene_lds_load(S, lds);
     if (k >= n) return;
-    const RtDevScene &S = *Sp;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     ray.dir = d3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
@@ -430,7 +454,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, i
     for (int i = 0; i < 6; i++) aux[i] = aux6 ? aux6[6 * k + i] : S.aux_init[i];
     Arena A;
     int start;
-    int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+    int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
     if (A.overflow) atomicAdd(overflow, 1);
     out_count[k] = count;
     for (int i = 0; i < max_hits; i++) {
@@ -459,28 +483,35 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene *Sp, i
  * Counts, for each ray, the events of the IDEAL-culling algorithm of SURVEY.md section 8d: a primitive is
  * tested only if the ray touches that primitive's own box; the box tests are those of a balanced hierarchy
  * over the leaves (2 per level on the way down plus 2 per leaf reached). */
-__global__ void __launch_bounds__(256) k_probe_work(const RtDevScene *Sp, int n, const double *org, const double *dir, unsigned long long *out /*6*/)
+__global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, const double *org, const double *dir, unsigned long long *out /*6*/)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const RtDevScene &S = Sv;
+    __shared__ SceneLds lds;
+    scene_lds_load(S, lds);
     if (k >= n) return;
-    const RtDevScene &S = *Sp;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     ray.dir = d3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
     unsigned leaf = 0, nleaves = 0;
+    const CullRay cr = cull_ray(ray, RT_INFINITY);
     for (int pc = 0; pc < S.n_prog; pc++) {
         int op = S.prog[pc].op;
-        if (op < OP_QUADRIC || op > OP_TORUS) continue;
-        nleaves++;
         bool hit = true;
-        if (pc > 0 && S.prog[pc - 1].op == OP_BOUND) hit = cull_box_hit(S.boxes[S.prog[pc - 1].a], ray, RT_INFINITY);
+        if (op == OP_CHAIN) {
+            int b = S.chains[S.prog[pc].a].box;
+            if (b >= 0) hit = cull_box_hit(S.boxes[b].lo, S.boxes[b].hi, cr);
+        } else if (op >= OP_QUADRIC && op <= OP_TORUS) {
+            if (pc > 0 && S.prog[pc - 1].op == OP_BOUND) hit = cull_box_hit(S.boxes[S.prog[pc - 1].a].lo, S.boxes[S.prog[pc - 1].a].hi, cr);
+        } else continue;
+        nleaves++;
         if (hit) leaf++;
     }
     unsigned levels = 0;
     while ((1u << levels) < nleaves) levels++;
     Arena A;
     int start;
-    int count = intersect_scene(S, ray, RT_INFINITY, A, start);
+    int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
     atomicAdd(&out[0], (unsigned long long)leaf);
     atomicAdd(&out[1], (unsigned long long)leaf);
     atomicAdd(&out[2], (unsigned long long)(2 * levels + 2 * leaf));
@@ -497,10 +528,10 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene *Sp, int n,
  * pixel GATHERS its (on average four) contributions in the reference's loop order -- tile x outer, tile y
  * inner, sample index, corner -- from a per-tile-pixel contributor table built once from the blue-noise
  * tile, which reproduces the reference's float accumulation bit for bit and needs no atomics. */
-__global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene *Sp, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
+__global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
                                                       int y0, int y1, float *im2 /*[3][rows][nW]*/, float *wt2 /*[rows][nW]*/)
 {
-    const RtDevScene &S = *Sp;
+    const RtDevScene &S = Sv;
     int px = blockIdx.x * blockDim.x + threadIdx.x;
     int py = y0 + blockIdx.y;
     if (px >= g.nW || py >= y1) return;
