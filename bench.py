@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=float, default=64.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opts", default=os.environ.get("RT_OPTS", ""), help="library tunables for A/B runs: name=value,...")
     args = ap.parse_args()
 
     import torch
@@ -58,6 +59,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    for kv in filter(None, args.opts.split(",")):
+        name, val = kv.split("=")
+        if rt.rt_lib().rt_set_option(name.encode(), int(val)):
+            raise SystemExit("bad --opts entry %r" % kv)
     W, H, spp = args.width, args.height, args.spp
     fs = rt.FrontScene(args.scene, "fastblue", optimize=True)
     gs = rt.GpuScene(fs.desc)

@@ -206,8 +206,9 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     int      nlist;
     int      top;           /* first free hit slot */
     int      overflow;
+    int      bail;          /* LITE interpreter met a rare, register-hungry feature: redo this ray in the FULL kernel */
 #ifdef RT_PHASE_PROF
-    int      prof[4];       /* cycles: [1] BVH candidate search, [2] primitive tests, [3] whole intersect */
+    int      prof[12];      /* cycles: [1] BVH candidate search, [2] primitive tests, [3] whole intersect, [4] chain setup, [5] wrappers, [6] region fold, [7] cull_ray */
 #endif
 };
 #ifdef RT_PHASE_PROF
@@ -600,6 +601,39 @@ __device__ int region_candidates(const RtDevScene &S, SceneLds &L, const RtRegio
     return n;
 }
 
+/* Can psModel->Intersect(ray) be non-empty at all?  false only when the ray misses every conservative box of a
+   scene whose root is one union region (or one boxed chain): then the hit list is empty, the radiance along a
+   primary ray is black and the irradiance along a shadow ray is unoccluded -- no need to run the interpreter. */
+__device__ bool scene_may_hit(const RtDevScene &S, SceneLds &L, const DRay &wray, double tmax)
+{
+    if (S.root_cull == 0) return true;
+    const CullRay cr = cull_ray(wray, tmax);
+    if (S.root_cull == 2) return cull_box_hit(S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi, cr);
+    const RtRegion &rg = S.regions[S.root_cull_arg];
+    if (rg.n_always > 0) return true;
+    if (rg.bvh_root < 0) return false;
+    const int lane = threadIdx.x;
+    int sp = 0, node = rg.bvh_root;
+    for (;;) {
+        int32_t child[4];
+        unsigned hit;
+        if (node < RT_LDS_BVH_NODES) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
+        else hit = bvh4_test((const double *)(S.bvh + node), cr, child);
+        for (int k = 3; k >= 0; k--) {
+            if (!(hit & (1u << k))) continue;
+            if (child[k] < 0) return true;
+            if (sp < RT_BVH_STACK) L.stack[sp++][lane] = (uint16_t)child[k];
+            else return true;
+        }
+        if (sp == 0) return false;
+        node = L.stack[--sp][lane];
+    }
+}
+
+/* LITE = true compiles the rare, register-hungry features out (torus quartics here; texture call-outs, propagators
+   and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
+   The split keeps the common kernels small enough for several waves per SIMD. */
+template <bool LITE>
 __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
@@ -607,12 +641,18 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
     int nrf = 0;
     int depth = 0;
     rs[0] = wray;
-    const CullRay cr = cull_ray(wray, tmax);
-    A.nlist = 0; A.top = 0; A.overflow = 0;
 #ifdef RT_PHASE_PROF
-    A.prof[0] = A.prof[1] = A.prof[2] = A.prof[3] = 0;
+    long long t_cr = clock64();
+#endif
+    const CullRay cr = cull_ray(wray, tmax);
+    A.nlist = 0; A.top = 0; A.overflow = 0; A.bail = 0;
+#ifdef RT_PHASE_PROF
+    for (int q = 0; q < 12; q++) A.prof[q] = 0;
 #endif
     PROF_BEGIN(t_all);
+#ifdef RT_PHASE_PROF
+    A.prof[7] = (int)(clock64() - t_cr);
+#endif
     int pc = 0;
     for (;;) {
         const RtInstr in = S.prog[pc];
@@ -641,7 +681,9 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
         case OP_QUADRIC: { PROF_BEGIN(tp); quadric_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_POLY:    { PROF_BEGIN(tp); poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_SLAB:    { PROF_BEGIN(tp); slab_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
-        case OP_TORUS:   { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_TORUS:
+            if constexpr (LITE) { A.bail = 1; goto done; }
+            else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
@@ -710,6 +752,7 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
             break;
         }
         case OP_CHAIN: {
+            PROF_BEGIN(tc);
             const RtChain &ch = S.chains[in.a];
             if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b) goto region_ret; break; }
             DRay r = rs[depth];
@@ -721,16 +764,20 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
                 r = nr;
             }
             const int before = A.nlist;
+            PROF_END(A, 4, tc);
             {
                 PROF_BEGIN(tp);
                 switch (ch.prim_op) {
                 case OP_QUADRIC: quadric_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
                 case OP_POLY:    poly_hits(S.prims[ch.prim], (uint16_t)ch.prim, S.planes, r, A, in.tag); break;
                 case OP_SLAB:    slab_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
-                default:         torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
+                default:
+                    if constexpr (LITE) { A.bail = 1; goto done; }
+                    else { torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break; }
                 }
                 PROF_END(A, 2, tp);
             }
+            PROF_BEGIN(tw);
             if (A.nlist > before) {
                 const int li = A.nlist - 1, s0 = A.l_start[li], c = A.l_count[li];
                 for (int w = 0; w < ch.n_wrap; w++) {
@@ -755,11 +802,13 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
                     }
                 }
             }
+            PROF_END(A, 5, tw);
             if (in.b) goto region_ret;
             break;
         }
         case OP_RET:
         region_ret: {
+            PROF_BEGIN(tr);
             /* one region child done: fold the non-empty lists in the union tree's own order */
             RegionFrame &f = rf[nrf - 1];
             const RtRegion &rg = S.regions[f.region];
@@ -783,6 +832,7 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
                 nrf--;
                 pc = rg.end_pc;
             }
+            PROF_END(A, 6, tr);
             break;
         }
         case OP_ANGCLIP: {                                      /* AngularClip::Intersect, Solids.cpp:1224-1241 */
@@ -810,6 +860,7 @@ __device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wra
     }
 done:
     PROF_END(A, 3, t_all);
+    if (A.bail) { start = 0; return 0; }
     if (A.nlist > 0 && A.l_tag[A.nlist - 1] == 0) { start = A.l_start[A.nlist - 1]; return A.l_count[A.nlist - 1]; }
     start = 0;
     return 0;
@@ -996,10 +1047,16 @@ __device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
     return r;
 }
 
-/* TransformNormals, Shade.cpp:264-284 */
-__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux)
+/* TransformNormals, Shade.cpp:264-284.  LITE: a hit with queued texture call-outs sets bail instead. */
+template <bool LITE>
+__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail)
 {
     h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat;
+    if constexpr (LITE) {
+        if (hr.ntex) { bail = true; return; }
+        for (int pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) h.n = covec_mat(h.n, S.affines[pa].minv);
+        return;
+    }
     int it = 0, nt = hr.ntex;
     int pa;
     for (pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) {

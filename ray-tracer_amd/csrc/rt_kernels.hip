@@ -94,14 +94,10 @@ __global__ void k_probe_camera(const RtDevScene Sv, int n, const double *v2, con
     dir[3 * k] = r.dir.x; dir[3 * k + 1] = r.dir.y; dir[3 * k + 2] = r.dir.z;
 }
 
-/* root frames for samples [first, first+n) of the grid; or for user rays (probe) when rays != 0 */
-__global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
+/* root ray k of a chunk: sample first + k of the grid, or user ray k (probes) */
+RT_DEV void root_ray(const RtDevScene &S, const RtSampleGrid &g, int64_t first, int k, const double *rays_org, const double *rays_dir, const double *rays_aux,
+                     DRay &r, double *aux)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const RtDevScene &S = Sv;
-    double aux[6];
-    DRay r;
     if (rays_org) {
         r.org = d3(rays_org[3 * k], rays_org[3 * k + 1], rays_org[3 * k + 2]);
         r.dir = d3(rays_dir[3 * k], rays_dir[3 * k + 1], rays_dir[3 * k + 2]);
@@ -111,36 +107,114 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleG
         sample_at(S, g, first + k, pos, v, aux);
         r = camera_emit(S.cam, v[0], v[1], aux[0], aux[1]);     /* CastFunction, RayTracer2020.cpp:20-31 */
     }
-    d3_store(P.f_ray, P.fcap, 0, k, r.org);
-    d3_store(P.f_ray, P.fcap, 3, k, r.dir);
+}
+RT_DEV void root_frame(const RtPipe &P, int f, int k, const DRay &r, const double *aux)
+{
+    d3_store(P.f_ray, P.fcap, 0, f, r.org);
+    d3_store(P.f_ray, P.fcap, 3, f, r.dir);
     for (int i = 0; i < 6; i++) P.aux[(size_t)i * P.ncap + k] = aux[i];
-    P.f_parent[k] = -1;
-    P.f_root[k] = k;
-    P.f_flags[k] = 0;
+    P.f_parent[f] = -1;
+    P.f_root[f] = k;
+    P.f_flags[f] = 0;
 }
 
-#ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 1     /* minimum waves per SIMD the tracing kernels are compiled for */
-#endif
-/* ------------------------------------------------------------------ k_visual */
-__global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
+/* root frames for rays [0, n) of a chunk, frame index = ray index */
+__global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
 {
-    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = f < f1;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double aux[6];
+    DRay r;
+    root_ray(Sv, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
+    root_frame(P, k, k, r, aux);
+}
+
+/* The same for scenes with a root cull (RtDevScene.root_cull): rays that miss every conservative box of the
+   scene (scene_may_hit) are finished here -- black -- and only the others become frames.  One workgroup
+   handles RT_GEN_SPAN consecutive rays and appends its survivors with ONE atomic, in ray order, so that the
+   frames of a workgroup of k_visual still come from one or two 40x40 sample tiles (coherent waves, even
+   workgroup run times). */
+#define RT_GEN_ITERS 6
+#define RT_GEN_SPAN  (RT_GEN_ITERS * 256)
+__global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir,
+                                                       const double *rays_aux, float *out_rgb, float *out_spec)
+{
     const RtDevScene &S = Sv;
+    __shared__ SceneLds lds;
+    __shared__ int wave_count[RT_GEN_ITERS][4], wave_base[RT_GEN_ITERS][4], block_base;
+    scene_lds_load(S, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * RT_GEN_SPAN;
+    unsigned keep_bits = 0;
+    unsigned long long prefix = 0;          /* 7 bits per iteration: survivors before this lane in its wave */
+    for (int it = 0; it < RT_GEN_ITERS; it++) {
+        int k = k0 + it * 256 + threadIdx.x;
+        bool keep = false;
+        if (k < n) {
+            double aux[6];
+            DRay r;
+            root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
+            keep = scene_may_hit(S, lds, r, RT_INFINITY);
+            if (!keep) {
+                if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
+                if (out_spec) for (int i = 0; i < RT_NSPEC; i++) out_spec[(size_t)k * RT_NSPEC + i] = 0.0f;
+            }
+        }
+        unsigned long long b = __ballot(keep);
+        if (keep) keep_bits |= 1u << it;
+        prefix |= (unsigned long long)__popcll(b & ((1ull << lane) - 1ull)) << (7 * it);
+        if (lane == 0) wave_count[it][wave] = __popcll(b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int it = 0; it < RT_GEN_ITERS; it++)
+            for (int w = 0; w < 4; w++) { wave_base[it][w] = total; total += wave_count[it][w]; }
+        block_base = total > 0 ? atomicAdd(&P.counters[CTR_FRAMES], total) : 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < RT_GEN_ITERS; it++) {
+        if (!(keep_bits & (1u << it))) continue;
+        int k = k0 + it * 256 + threadIdx.x;
+        double aux[6];
+        DRay r;
+        root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
+        root_frame(P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux);
+    }
+}
+
+/* ------------------------------------------------------------------ k_visual
+ * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
+ * LITE = true is the common kernel: a ray that meets a torus, a textured hit, a propagating medium or a spectral
+ * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
+template <bool LITE>
+__global__ void __launch_bounds__(256, LITE ? 2 : 1) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
+{
+    const RtDevScene &S = Sv;
+    int f;
+    bool live;
+    if constexpr (LITE) {
+        f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+        live = f < f1;
+    } else {
+        const int n = P.counters[CTR_SLOW_V];
+        if ((int)(blockIdx.x * blockDim.x) >= n) return;
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        live = i < n;
+        f = live ? P.slow_v[i] : 0;
+    }
     __shared__ SceneLds lds;
     scene_lds_load(S, lds);
 #ifdef RT_PHASE_PROF
     long long prof_t0 = clock64();
-    int prof_v[4] = { 0, 0, 0, 0 };
+    int prof_v[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     int n_shadow = 0;
     unsigned mask = 0;
-    DRay sdir[1];
-    (void)sdir;
     D3 Ppt = d3(0, 0, 0);
     double aux[6];
     int flags = 0;
+    bool bail = false;
     if (live) {
         flags = P.f_flags[f] & FR_KEEP_MASK;
         DRay ray;
@@ -150,19 +224,22 @@ __global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene
         for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
         Arena A;
         int start;
-        int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
+        int count = intersect_scene<LITE>(S, lds, ray, RT_INFINITY, A, start);
         if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+        bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
-        for (int q = 1; q < 4; q++) prof_v[q] = A.prof[q];
+        for (int q = 1; q < 8; q++) prof_v[q] = A.prof[q];
+        prof_v[8] = (int)(clock64() - prof_t0);
 #endif
         /* Shade.cpp:424-432: regularise into (0, t, ...) */
         int i = 0, pm = 0;
         if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
         double t = 0.0;
         Spec tr = spec_const(1.0f), R = spec_const(0.0f);
-        for (; i < count; i++) {
+        for (; i < count && !bail; i++) {
             ShadeHit h;
-            transform_normals(S, ray, A.h[start + i], h, aux);
+            transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
+            if (bail) break;
             const RtMaterialDev &mp = S.mats[pm];
             if (mp.luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
                 R = spec_load(mp.color);
@@ -170,10 +247,13 @@ __global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene
                 break;
             }
             if (mp.prop) {
-                Spec ptr, pst;
-                propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
-                tr = tr * ptr;
-                R = R + pst;
+                if constexpr (LITE) { bail = true; break; }
+                else {
+                    Spec ptr, pst;
+                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+                    tr = tr * ptr;
+                    R = R + pst;
+                }
             }
             const RtMaterialDev &mh = S.mats[h.mat];
             if ((mp.refr != mh.refr) || (mh.luster != RT_MAT_TRANSPARENT)) {
@@ -182,8 +262,11 @@ __global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene
                 consistent_normal(ray, h, vE, cvN, fNE);
                 Spec color = spec_load(mh.color);
                 if (spectral_metal(mh.luster)) {                /* Q3 */
-                    color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC + RT_NSPEC);
-                    F = 1.0;
+                    if constexpr (LITE) { bail = true; break; }
+                    else {
+                        color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC + RT_NSPEC);
+                        F = 1.0;
+                    }
                 } else
                     fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
                 int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
@@ -224,26 +307,36 @@ __global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene
                 pm = h.mat;
             }
         }
-        if (!(flags & FR_FINAL) && S.mats[pm].prop) {           /* Shade.cpp:512-516 */
-            Spec ptr, pst;
-            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), S.mats[pm].color, ptr, pst);
-            spec_store(P.f_fin, P.fcap, f, tr * pst);
-            flags |= FR_FIN;
+        if (!bail && !(flags & FR_FINAL) && S.mats[pm].prop) {  /* Shade.cpp:512-516 */
+            if constexpr (LITE) bail = true;
+            else {
+                Spec ptr, pst;
+                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), S.mats[pm].color, ptr, pst);
+                spec_store(P.f_fin, P.fcap, f, tr * pst);
+                flags |= FR_FIN;
+            }
         }
-        spec_store(P.f_R, P.fcap, f, R);
-        spec_store(P.f_tr, P.fcap, f, tr);
+        if (!bail) {
+            spec_store(P.f_R, P.fcap, f, R);
+            spec_store(P.f_tr, P.fcap, f, tr);
+        }
+    }
+    if constexpr (LITE) {
+        if (bail) { n_shadow = 0; mask = 0; }
+        int slot = wave_alloc(bail ? 1 : 0, &P.counters[CTR_SLOW_V]);
+        if (bail) P.slow_v[slot] = f;
     }
     /* append this lane's shadow rays to the queue: one atomic per wave */
     int base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
-    for (int q = 0; q < 4; q++) {           /* per-wave maxima, in units of 16 cycles */
+    for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 16 cycles */
         int v = prof_v[q];
         for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
-        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PRIMARY + q], v >> 4);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 4);
     }
 #endif
-    if (!live) return;
+    if (!live || bail) return;
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
     P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
     P.f_flags[f] = flags;
@@ -264,64 +357,93 @@ __global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_visual(const RtDevScene
     }
 }
 
-/* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359 */
-__global__ void __launch_bounds__(256, RT_TRACE_WAVES) k_shadow(const RtDevScene Sv, RtPipe P, int n)
+/* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
+ * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
+template <bool LITE>
+__global__ void __launch_bounds__(256, LITE ? 3 : 1) k_shadow(const RtDevScene Sv, RtPipe P, int n)
 {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
+    int s;
+    bool live;
+    if constexpr (LITE) {
+        s = blockIdx.x * blockDim.x + threadIdx.x;
+        live = s < n;
+    } else {
+        const int m = P.counters[CTR_SLOW_S];
+        if ((int)(blockIdx.x * blockDim.x) >= m) return;
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        live = i < m;
+        s = live ? P.slow_s[i] : 0;
+    }
     __shared__ SceneLds lds;
     scene_lds_load(S, lds);
-    if (s >= n) return;
-    DRay ray;
-    ray.org = d3_fetch(P.s_ray, P.scap, 0, s);
-    ray.dir = d3_fetch(P.s_ray, P.scap, 3, s);
-    const RtLightDev &l = S.lights[P.s_light[s]];
-    double aux[6];
-    int root = P.s_root[s];
-    for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
-    double r2 = dot(ray.dir, ray.dir);
-    Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
-    Arena A;
-    int start;
-    int count = intersect_scene(S, lds, ray, 1.0, A, start);
-    if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
-    int i = 0, pm = 0;
-    if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
-    double t = 0.0;
-    Spec tr = spec_const(1.0f);
-    bool blocked = false;
-    for (; i < count && A.h[start + i].t < 1.0 - RT_EPSILON; i++) {
-        ShadeHit h;
-        transform_normals(S, ray, A.h[start + i], h, aux);
-        const RtMaterialDev &mp = S.mats[pm], &mh = S.mats[h.mat];
-        if (mp.luster != RT_MAT_TRANSPARENT || mh.luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
-        if (mp.prop) {
-            Spec ptr, pst;
-            propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
-            tr = tr * ptr;
+    bool bail = false;
+    if (live) {
+        DRay ray;
+        ray.org = d3_fetch(P.s_ray, P.scap, 0, s);
+        ray.dir = d3_fetch(P.s_ray, P.scap, 3, s);
+        const RtLightDev &l = S.lights[P.s_light[s]];
+        double aux[6];
+        int root = P.s_root[s];
+        for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
+        double r2 = dot(ray.dir, ray.dir);
+        Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
+        Arena A;
+        int start;
+        int count = intersect_scene<LITE>(S, lds, ray, 1.0, A, start);
+        if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+        bail = A.bail != 0;
+        int i = 0, pm = 0;
+        if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
+        double t = 0.0;
+        Spec tr = spec_const(1.0f);
+        bool blocked = false;
+        for (; !bail && i < count && A.h[start + i].t < 1.0 - RT_EPSILON; i++) {
+            ShadeHit h;
+            transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
+            if (bail) break;
+            const RtMaterialDev &mp = S.mats[pm], &mh = S.mats[h.mat];
+            if (mp.luster != RT_MAT_TRANSPARENT || mh.luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
+            if (mp.prop) {
+                if constexpr (LITE) { bail = true; break; }
+                else {
+                    Spec ptr, pst;
+                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+                    tr = tr * ptr;
+                }
+            }
+            if (mp.refr != mh.refr) {
+                D3 vE, cvN;
+                double fNE, F = 0.0, fNT = 0.0;
+                consistent_normal(ray, h, vE, cvN, fNE);
+                fresnel_real(fNE, mh.refr, mp.refr, F, fNT);
+                if (F == 1.0) { blocked = true; break; }
+                tr = tr * (1.0 - F);
+            }
+            t = h.t;
+            pm = h.mat;
         }
-        if (mp.refr != mh.refr) {
-            D3 vE, cvN;
-            double fNE, F = 0.0, fNT = 0.0;
-            consistent_normal(ray, h, vE, cvN, fNE);
-            fresnel_real(fNE, mh.refr, mp.refr, F, fNT);
-            if (F == 1.0) { blocked = true; break; }
-            tr = tr * (1.0 - F);
+        if (!bail) {
+            Spec out;
+            if (blocked) out = spec_const(0.0f);
+            else {
+                if (S.mats[pm].prop && S.mats[pm].luster == RT_MAT_TRANSPARENT) {
+                    if constexpr (LITE) bail = true;
+                    else {
+                        Spec ptr, pst;
+                        propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), S.mats[pm].color, ptr, pst);
+                        tr = tr * ptr;
+                    }
+                }
+                out = E * tr;
+            }
+            if (!bail) spec_store(P.s_E, P.scap, s, out);
         }
-        t = h.t;
-        pm = h.mat;
     }
-    Spec out;
-    if (blocked) out = spec_const(0.0f);
-    else {
-        if (S.mats[pm].prop && S.mats[pm].luster == RT_MAT_TRANSPARENT) {
-            Spec ptr, pst;
-            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), S.mats[pm].color, ptr, pst);
-            tr = tr * ptr;
-        }
-        out = E * tr;
+    if constexpr (LITE) {
+        int slot = wave_alloc(bail ? 1 : 0, &P.counters[CTR_SLOW_S]);
+        if (bail) P.slow_s[slot] = s;
     }
-    spec_store(P.s_E, P.scap, s, out);
 }
 
 /* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
@@ -454,7 +576,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
     for (int i = 0; i < 6; i++) aux[i] = aux6 ? aux6[6 * k + i] : S.aux_init[i];
     Arena A;
     int start;
-    int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
+    int count = intersect_scene<false>(S, lds, ray, RT_INFINITY, A, start);
     if (A.overflow) atomicAdd(overflow, 1);
     out_count[k] = count;
     for (int i = 0; i < max_hits; i++) {
@@ -464,7 +586,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
             D3 nn = hr.n;
             if (transform) {
                 ShadeHit h;
-                transform_normals(S, ray, hr, h, aux);
+                { bool nb = false; transform_normals<false>(S, ray, hr, h, aux, nb); }
                 nn = h.perturbed ? h.np : h.n;
             }
             out_t[o] = hr.t;
@@ -511,7 +633,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
     while ((1u << levels) < nleaves) levels++;
     Arena A;
     int start;
-    int count = intersect_scene(S, lds, ray, RT_INFINITY, A, start);
+    int count = intersect_scene<false>(S, lds, ray, RT_INFINITY, A, start);
     atomicAdd(&out[0], (unsigned long long)leaf);
     atomicAdd(&out[1], (unsigned long long)leaf);
     atomicAdd(&out[2], (unsigned long long)(2 * levels + 2 * leaf));

@@ -17,7 +17,7 @@
 
 enum { GEO_P = 0, GEO_N = 3, GEO_E = 6, GEO_HN = 9, GEO_FNE = 12, GEO_F = 13, GEO_FNT = 14, GEO_ETA = 15, GEO_W2 = 16, GEO_COUNT = 17 };
 enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT = 4 };
-enum { CTR_FRAMES = 0, CTR_SHADOW = 1, CTR_OVERFLOW = 2, CTR_PRIMARY = 3, CTR_SECONDARY = 4, CTR_SHADOWRAYS = 5, CTR_COUNT = 8 };
+enum { CTR_FRAMES = 0, CTR_OVERFLOW = 1, CTR_SHADOW = 2, CTR_SLOW_V = 3, CTR_SLOW_S = 4, CTR_PROF = 5, CTR_COUNT = 16 };   /* [CTR_SHADOW .. CTR_SLOW_S] are cleared together per level */
 
 typedef struct RtPipe {
     int     fcap, scap, ncap;   /* frame, shadow-ray and root capacities */
@@ -33,6 +33,7 @@ typedef struct RtPipe {
     double *s_ray;              /* 6 */
     int    *s_light, *s_root;
     float  *s_E;                /* 10 */
+    int    *slow_v, *slow_s;    /* frames / shadow rays the LITE kernels handed to the FULL ones: fcap, scap */
     int    *counters;           /* CTR_COUNT */
 } RtPipe;
 
