@@ -695,22 +695,61 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
 }
 
 /* Resample (Sampling.cpp:131-184), WRAP_CLAMP.  src: [planes][src_rows][src_n] -> dst laid out [planes][src_rows][dst_n] */
+/* One workgroup = 256 consecutive destinations of one source row.  The source span they read (256 * ratio + taps
+   floats) is staged in LDS once, padded by one word per 32 so that the lanes' strided reads (stride = the
+   decimation ratio) spread over the banks; with an integer ratio every destination has the same taps and those
+   are staged too.  The sums run in the reference's order (Sampling.cpp:158-176), in double. */
+#define RT_RS_SPAN  4608        /* floats of source per workgroup that fit the staging buffer */
+#define RT_RS_TAPS  520
+#define RT_RS_IDX(j) ((j) + ((j) >> 5))
 __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int planes, int rows, int n_src, int n_dst, RtTapTable T, float *dst)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    int row = blockIdx.y;
-    int pl = blockIdx.z;
-    if (id >= n_dst || row >= rows || pl >= planes) return;
+    __shared__ float  s_src[RT_RS_SPAN + RT_RS_SPAN / 32 + 2];
+    __shared__ double s_taps[RT_RS_TAPS];
+    const int id0 = blockIdx.x * blockDim.x, id = id0 + threadIdx.x;
+    const int row = blockIdx.y, pl = blockIdx.z;
     const float *s = src + ((size_t)pl * rows + row) * n_src;
-    int i0 = T.first[id], cnt = T.count[id];
+    const int last = (id0 + 255 < n_dst ? id0 + 255 : n_dst - 1);
+    const int base = T.first[id0], span = T.first[last] + T.count[last] - base;
+    const bool staged = span > 0 && span <= RT_RS_SPAN;
+    const bool utaps = T.uniform && T.max_count <= RT_RS_TAPS;
+    if (staged)
+        for (int j = threadIdx.x; j < span; j += 256) {
+            int is = base + j, i = is;
+            if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
+            s_src[RT_RS_IDX(j)] = s[i];
+        }
+    if (utaps) {
+        const double *p0 = T.taps + T.offset[0];
+        for (int k = threadIdx.x; k < T.max_count; k += 256) s_taps[k] = p0[k];
+    }
+    __syncthreads();
+    if (id >= n_dst) return;
+    const int i0 = T.first[id], cnt = T.count[id];
     const double *pf = T.taps + T.offset[id];
     double sum = 0.0, wsum = 0.0;
-    for (int k = 0; k < cnt; k++) {
-        int is = i0 + k, i = is;
-        if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
-        double y = (double)s[i], fw = pf[k];
-        sum += fw * y;
-        wsum += fw;
+    if (staged && utaps) {
+        const int j0 = i0 - base;
+        for (int k = 0; k < cnt; k++) {
+            double y = (double)s_src[RT_RS_IDX(j0 + k)], fw = s_taps[k];
+            sum += fw * y;
+            wsum += fw;
+        }
+    } else if (staged) {
+        const int j0 = i0 - base;
+        for (int k = 0; k < cnt; k++) {
+            double y = (double)s_src[RT_RS_IDX(j0 + k)], fw = pf[k];
+            sum += fw * y;
+            wsum += fw;
+        }
+    } else {
+        for (int k = 0; k < cnt; k++) {
+            int is = i0 + k, i = is;
+            if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
+            double y = (double)s[i], fw = pf[k];
+            sum += fw * y;
+            wsum += fw;
+        }
     }
     if (wsum != 0.0) sum /= wsum;
     dst[((size_t)pl * rows + row) * n_dst + id] = (float)sum;

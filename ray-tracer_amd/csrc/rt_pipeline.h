@@ -56,4 +56,6 @@ typedef struct RtSplatTable {   /* contributors of each pixel of a (40+2)^2 tile
 typedef struct RtTapTable {     /* ComputeTaps / Resample, Sampling.cpp:86-184 */
     const double *taps;
     const int    *first, *count, *offset;
+    int           uniform;      /* every destination has the same number of taps with bit-identical values (integer ratios) */
+    int           max_count;
 } RtTapTable;
