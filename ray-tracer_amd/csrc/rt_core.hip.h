@@ -333,34 +333,40 @@ RT_DEV int extent_test(const double *lo, const double *hi, const DRay &ray)
 }
 
 /* this build's culling test: does the world ray, t in [0, tmax], touch the (padded, conservative) box?
-   Not part of the reference's arithmetic: any conservative test gives the same hit lists.  The reciprocal
-   direction is formed once per ray. */
-struct CullRay { double o[3], inv[3], tmax; int zmask; };
+   Not part of the reference's arithmetic -- any conservative test gives the same hit lists -- so it may use
+   fused multiply-adds (the reference path is compiled with contraction off): per bound t = fma(b, inv, -o*inv).
+   Rounding: -o*inv carries |o*inv| * 2^-53, the fma another half ulp of t; `slack` covers both. */
+struct CullRay { double o[3], inv[3], noi[3], tmax, slack; int zmask, neg; };
 RT_DEV CullRay cull_ray(const DRay &r, double tmax)
 {
     CullRay c;
     c.o[0] = r.org.x; c.o[1] = r.org.y; c.o[2] = r.org.z;
     const double d[3] = { r.dir.x, r.dir.y, r.dir.z };
-    c.zmask = 0;
+    c.zmask = 0; c.neg = 0;
+    c.slack = 0.0;
     for (int i = 0; i < 3; i++) {
-        if (d[i] != 0.0) c.inv[i] = 1.0 / d[i];
-        else { c.inv[i] = 0.0; c.zmask |= 1 << i; }
+        if (d[i] != 0.0) { c.inv[i] = 1.0 / d[i]; c.noi[i] = -(c.o[i] * c.inv[i]); c.slack += fabs(c.noi[i]); if (d[i] < 0.0) c.neg |= 1 << i; }
+        else { c.inv[i] = 0.0; c.noi[i] = 0.0; c.zmask |= 1 << i; }
     }
+    c.slack *= 1.0e-15;
     c.tmax = tmax;
     return c;
+}
+RT_DEV bool cull_interval_ok(double t0, double t1, const CullRay &c)
+{
+    return t0 - t1 <= c.slack + (fabs(t0) + fabs(t1)) * 1.0e-15;
 }
 RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
 {
     double t0 = 0.0, t1 = c.tmax;
     for (int i = 0; i < 3; i++) {
         if (!(c.zmask & (1 << i))) {
-            double ta = (lo[i] - c.o[i]) * c.inv[i], tb = (hi[i] - c.o[i]) * c.inv[i];
+            double ta = __builtin_fma(lo[i], c.inv[i], c.noi[i]), tb = __builtin_fma(hi[i], c.inv[i], c.noi[i]);
             t0 = fmax(t0, fmin(ta, tb)); t1 = fmin(t1, fmax(ta, tb));
         } else if (c.o[i] < lo[i] || c.o[i] > hi[i])
             return false;
     }
-    /* three roundings per bound (reciprocal, difference, product): widen by a few ulps so the test stays conservative */
-    return t0 - t0 * 8e-16 <= t1 + fabs(t1) * 8e-16;
+    return cull_interval_ok(t0, t1, c);
 }
 
 /* ================================================================== primitives */
@@ -526,22 +532,27 @@ RT_DEV int region_gap(const RtDevScene &S, const RtRegion &rg, int a, int b)
     return x < y ? x : y;
 }
 
-/* workgroup-shared staging: the top of the scene's BVH and the per-lane traversal stacks (blockDim.x == 256) */
-struct SceneLds {
-    double   bvh[RT_LDS_BVH_NODES * (sizeof(RtBvhNode) / 8)];
-    uint16_t stack[RT_BVH_STACK][256];
-};
+/* workgroup-shared staging in dynamic LDS (size RtDevScene.lds_bytes, blockDim.x == 256): the first n_bvh_lds
+   nodes of the scene's BVH, then the per-lane traversal stacks */
+struct SceneLds { const double *bvh; uint16_t *stack; int n_nodes; };
+#define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * 256 + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
-RT_DEV void scene_lds_load(const RtDevScene &S, SceneLds &L)
+RT_DEV SceneLds scene_lds_load(const RtDevScene &S)
 {
-    int n = S.n_bvh < RT_LDS_BVH_NODES ? S.n_bvh : RT_LDS_BVH_NODES;
-    int words = n * (int)(sizeof(RtBvhNode) / 8);
+    extern __shared__ double rt_dyn_lds[];
+    SceneLds L;
+    L.n_nodes = S.n_bvh_lds;
+    int words = L.n_nodes * (int)(sizeof(RtBvhNode) / 8);
     const double *src = (const double *)S.bvh;
-    for (int k = threadIdx.x; k < words; k += blockDim.x) L.bvh[k] = src[k];
+    for (int k = threadIdx.x; k < words; k += blockDim.x) rt_dyn_lds[k] = src[k];
+    L.bvh = rt_dyn_lds;
+    L.stack = (uint16_t *)(rt_dyn_lds + words);
     __syncthreads();
+    return L;
 }
 
-/* one 4-wide node: test the four child boxes together */
+/* one 4-wide node: test the four child boxes together; the near/far plane of every axis is picked by the sign
+   of the ray direction, so a bound costs one fma and one min/max */
 RT_DEV unsigned bvh4_test(const double *nb, const CullRay &c, int32_t child[4])
 {
     double t0[4], t1[4];
@@ -550,9 +561,10 @@ RT_DEV unsigned bvh4_test(const double *nb, const CullRay &c, int32_t child[4])
     for (int d = 0; d < 3; d++) {
         const double *lo = nb + 4 * d, *hi = nb + 12 + 4 * d;
         if (!(c.zmask & (1 << d))) {
+            const double *nr = (c.neg & (1 << d)) ? hi : lo, *fr = (c.neg & (1 << d)) ? lo : hi;
             for (int k = 0; k < 4; k++) {
-                double ta = (lo[k] - c.o[d]) * c.inv[d], tb = (hi[k] - c.o[d]) * c.inv[d];
-                t0[k] = fmax(t0[k], fmin(ta, tb)); t1[k] = fmin(t1[k], fmax(ta, tb));
+                t0[k] = fmax(t0[k], __builtin_fma(nr[k], c.inv[d], c.noi[d]));
+                t1[k] = fmin(t1[k], __builtin_fma(fr[k], c.inv[d], c.noi[d]));
             }
         } else {
             for (int k = 0; k < 4; k++) if (c.o[d] < lo[k] || c.o[d] > hi[k]) alive &= ~(1u << k);
@@ -562,14 +574,14 @@ RT_DEV unsigned bvh4_test(const double *nb, const CullRay &c, int32_t child[4])
     unsigned hit = 0;
     for (int k = 0; k < 4; k++) {
         child[k] = ch[k];
-        if ((alive & (1u << k)) && child[k] != RT_BVH_EMPTY && t0[k] - t0[k] * 8e-16 <= t1[k] + fabs(t1[k]) * 8e-16) hit |= 1u << k;
+        if ((alive & (1u << k)) && child[k] != RT_BVH_EMPTY && cull_interval_ok(t0[k], t1[k], c)) hit |= 1u << k;
     }
     return hit;
 }
 
 /* candidates of a union region: children with unbounded boxes plus those whose box the ray touches,
    ascending (= the reference's evaluation order) */
-__device__ int region_candidates(const RtDevScene &S, SceneLds &L, const RtRegion &rg, const CullRay &cr, uint16_t *cand, int &overflow)
+__device__ int region_candidates(const RtDevScene &S, const SceneLds &L, const RtRegion &rg, const CullRay &cr, uint16_t *cand, int &overflow)
 {
     int n = 0;
     for (int k = 0; k < rg.n_always; k++) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)S.region_always[rg.always0 + k]; else overflow = 1; }
@@ -580,16 +592,16 @@ __device__ int region_candidates(const RtDevScene &S, SceneLds &L, const RtRegio
         for (;;) {
             int32_t child[4];
             unsigned hit;
-            if (node < RT_LDS_BVH_NODES) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
+            if (node < L.n_nodes) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
             else hit = bvh4_test((const double *)(S.bvh + node), cr, child);
             for (int k = 3; k >= 0; k--) {
                 if (!(hit & (1u << k))) continue;
                 if (child[k] < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~child[k]); else overflow = 1; }
-                else if (sp < RT_BVH_STACK) L.stack[sp++][lane] = (uint16_t)child[k];
+                else if (sp < RT_BVH_STACK) RT_LDS_STACK(L, sp++, lane) = (uint16_t)child[k];
                 else overflow = 1;
             }
             if (sp == 0) break;
-            node = L.stack[--sp][lane];
+            node = RT_LDS_STACK(L, --sp, lane);
         }
     }
     for (int i = 1; i < n; i++) {           /* insertion sort: n is small */
@@ -604,7 +616,7 @@ __device__ int region_candidates(const RtDevScene &S, SceneLds &L, const RtRegio
 /* Can psModel->Intersect(ray) be non-empty at all?  false only when the ray misses every conservative box of a
    scene whose root is one union region (or one boxed chain): then the hit list is empty, the radiance along a
    primary ray is black and the irradiance along a shadow ray is unoccluded -- no need to run the interpreter. */
-__device__ bool scene_may_hit(const RtDevScene &S, SceneLds &L, const DRay &wray, double tmax)
+__device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax)
 {
     if (S.root_cull == 0) return true;
     const CullRay cr = cull_ray(wray, tmax);
@@ -617,16 +629,16 @@ __device__ bool scene_may_hit(const RtDevScene &S, SceneLds &L, const DRay &wray
     for (;;) {
         int32_t child[4];
         unsigned hit;
-        if (node < RT_LDS_BVH_NODES) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
+        if (node < L.n_nodes) hit = bvh4_test(L.bvh + (size_t)node * (sizeof(RtBvhNode) / 8), cr, child);
         else hit = bvh4_test((const double *)(S.bvh + node), cr, child);
         for (int k = 3; k >= 0; k--) {
             if (!(hit & (1u << k))) continue;
             if (child[k] < 0) return true;
-            if (sp < RT_BVH_STACK) L.stack[sp++][lane] = (uint16_t)child[k];
+            if (sp < RT_BVH_STACK) RT_LDS_STACK(L, sp++, lane) = (uint16_t)child[k];
             else return true;
         }
         if (sp == 0) return false;
-        node = L.stack[--sp][lane];
+        node = RT_LDS_STACK(L, --sp, lane);
     }
 }
 
@@ -634,7 +646,7 @@ __device__ bool scene_may_hit(const RtDevScene &S, SceneLds &L, const DRay &wray
    and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
    The split keeps the common kernels small enough for several waves per SIMD. */
 template <bool LITE>
-__device__ int intersect_scene(const RtDevScene &S, SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
+__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
     RegionFrame rf[RT_MAX_REGION_DEPTH];

@@ -175,6 +175,7 @@ typedef struct RtDevScene {
     const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
     int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
+    int32_t n_bvh_lds, lds_bytes;       /* BVH nodes staged in LDS; dynamic LDS bytes of every kernel that traces */
     int32_t root_cull, root_cull_arg;   /* 0: none; 1: the whole program is union region root_cull_arg; 2: ... is one chain with box root_cull_arg */
     float   ambient[RT_NSPEC];
     float   spec2rgb[RT_NSPEC][3];

@@ -140,9 +140,8 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
                                                        const double *rays_aux, float *out_rgb, float *out_spec)
 {
     const RtDevScene &S = Sv;
-    __shared__ SceneLds lds;
     __shared__ int wave_count[RT_GEN_ITERS][4], wave_base[RT_GEN_ITERS][4], block_base;
-    scene_lds_load(S, lds);
+    const SceneLds lds = scene_lds_load(S);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = blockIdx.x * RT_GEN_SPAN;
     unsigned keep_bits = 0;
@@ -183,12 +182,18 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
     }
 }
 
+#ifndef RT_LITE_VISUAL_WAVES
+#define RT_LITE_VISUAL_WAVES 3   /* minimum waves per SIMD the common kernels are compiled for */
+#endif
+#ifndef RT_LITE_SHADOW_WAVES
+#define RT_LITE_SHADOW_WAVES 4
+#endif
 /* ------------------------------------------------------------------ k_visual
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
  * LITE = true is the common kernel: a ray that meets a torus, a textured hit, a propagating medium or a spectral
  * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
 template <bool LITE>
-__global__ void __launch_bounds__(256, LITE ? 2 : 1) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
+__global__ void __launch_bounds__(256, LITE ? RT_LITE_VISUAL_WAVES : 1) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
 {
     const RtDevScene &S = Sv;
     int f;
@@ -203,8 +208,7 @@ __global__ void __launch_bounds__(256, LITE ? 2 : 1) k_visual(const RtDevScene S
         live = i < n;
         f = live ? P.slow_v[i] : 0;
     }
-    __shared__ SceneLds lds;
-    scene_lds_load(S, lds);
+    const SceneLds lds = scene_lds_load(S);
 #ifdef RT_PHASE_PROF
     long long prof_t0 = clock64();
     int prof_v[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(256, LITE ? 2 : 1) k_visual(const RtDevScene S
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
 template <bool LITE>
-__global__ void __launch_bounds__(256, LITE ? 3 : 1) k_shadow(const RtDevScene Sv, RtPipe P, int n)
+__global__ void __launch_bounds__(256, LITE ? RT_LITE_SHADOW_WAVES : 1) k_shadow(const RtDevScene Sv, RtPipe P, int n)
 {
     const RtDevScene &S = Sv;
     int s;
@@ -375,8 +379,7 @@ __global__ void __launch_bounds__(256, LITE ? 3 : 1) k_shadow(const RtDevScene S
         live = i < m;
         s = live ? P.slow_s[i] : 0;
     }
-    __shared__ SceneLds lds;
-    scene_lds_load(S, lds);
+    const SceneLds lds = scene_lds_load(S);
     bool bail = false;
     if (live) {
         DRay ray;
@@ -566,8 +569,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
-    __shared__ SceneLds lds;
-    scene_lds_load(S, lds);
+    const SceneLds lds = scene_lds_load(S);
     if (k >= n) return;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
@@ -609,8 +611,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
-    __shared__ SceneLds lds;
-    scene_lds_load(S, lds);
+    const SceneLds lds = scene_lds_load(S);
     if (k >= n) return;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
