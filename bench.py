@@ -67,22 +67,15 @@ def main():
     fs = rt.FrontScene(args.scene, "fastblue", optimize=True)
     gs = rt.GpuScene(fs.desc)
     # contiguous row bands; every rank traces its own halo, so the data path has no exchange
-    rows = [(H * r) // world for r in range(world + 1)]
+    sh = rt.sharding
+    rows = sh.row_bands(H, world)
     row0, row1 = rows[rank], rows[rank + 1]
     planes = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    maxrows = max(rows[r + 1] - rows[r] for r in range(world))
 
     def step():
         st = gs.render_device(W, H, spp, planes.data_ptr(), stream, row0, row1 if world > 1 else 0)
-        if world > 1:
-            band = torch.zeros((3, maxrows, W), dtype=torch.float32, device="cuda")
-            band[:, : row1 - row0, :] = planes[:, row0:row1, :]
-            out = [torch.empty_like(band) for _ in range(world)] if rank == 0 else None
-            dist.gather(band, out, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    planes[:, rows[r]:rows[r + 1], :] = out[r][:, : rows[r + 1] - rows[r], :]
+        sh.gather_bands(planes, rows, rank, world, dist)
         return st
 
     def barrier():
@@ -147,20 +140,26 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total):
     s8 = np.concatenate([gs.samples(W, H, spp, t * 1600, 1600)[0] for t in picks], axis=0)
     m = len(s8)
     org, dr = gs.camera(s8[:, :2], s8[:, 2:])
-    work = np.zeros(8, dtype=np.float64)
+    work = np.zeros(9, dtype=np.float64)
     L = rt.rt_lib()
     L.rt_probe_work.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     rc = L.rt_probe_work(gs.h, m, org.ctypes.data_as(C.POINTER(C.c_double)), dr.ctypes.data_as(C.POINTER(C.c_double)), work.ctypes.data_as(C.POINTER(C.c_double)))
     if rc:
         return {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "note": "rt_probe_work failed: %s" % L.rt_last_error().decode()}
-    leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch = work
+    leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch, m_reach = work
+    if m_reach <= 0 or ms_per_launch <= 0:
+        return {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "note": "no ray reached k_visual"}
+    frac_reach = m_reach / m
+    m = m_reach         # per-ray figures are over the rays k_visual processes
     per_ray = (leaf * (W_AFFINE + W_QUADRIC) + boxes_ideal * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
     flops = per_ray * rays_per_launch
     ach = flops / (ms_per_launch * 1e-3) / 1e12
     return {"bound": "valu_fp64", "kernel": "k_visual", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
             "flops_per_ray": per_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch,
+            "rays_reaching_kernel": frac_reach,
             "events_per_ray": {"leaf_tests": leaf / m, "ideal_box_tests": boxes_ideal / m, "merged_hits": merged / m,
                                "shaded_boundaries": boundaries / m, "light_terms": lights / m}}
 

@@ -47,6 +47,13 @@ int  rt_render(rt_scene *s, const RtRenderDesc *rd, float *planes, RtStats *stat
    and what a multi-GPU caller gathers with RCCL. */
 int  rt_render_device(rt_scene *s, const RtRenderDesc *rd, float *planes_dev, RtStats *stats, void *hip_stream);
 
+/* Host-only planning of a row-sharded render (no counterpart in the reference, which renders whole images):
+   for output rows [rd->row0, rd->row1) of a FASTBLUE render, the supersample rows [out8[0], out8[1]) the vertical
+   filter reads (Sampling.cpp:144-154) and the blue-noise tile rows [out8[2], out8[2] + out8[3]) whose samples can
+   reach them through the bilinear splat; then nW, nH (Sampling.cpp:484-485) and the tile counts.  A rank that
+   traces exactly those tiles needs no exchange with its neighbours.  Needs no GPU. */
+int  rt_plan_rows(int sampler, const RtRenderDesc *rd, int *out8);
+
 /* ---- parity probes: the same device code paths, exposed per stage (host buffers) ------------- */
 
 /* Sample generation of the scene's sampling tile (Sampling.cpp:335-346 / 498-517): samples
@@ -75,14 +82,17 @@ int  rt_probe_sample_rgb(rt_scene *s, const RtRenderDesc *rd, float *out_rgb, in
 void rt_build_quasi_index(int *out, int prime, int n);
 void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);
 
-/* Measurement support for bench.py (no counterpart in the reference): sums over n rays of the ideal-culling
-   event counts of SURVEY.md section 8d (leaf tests, affine transforms, box tests, merged hits, shaded
-   boundaries, light terms), then the average duration (ms, HIP events on the render stream) and size (rays)
-   of the k_visual launches made since the previous call while option "time_kernels" was 1. */
-int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out8);
+/* Measurement support for bench.py (no counterpart in the reference): sums, over those of the n rays that reach
+   k_visual (rays that miss every box of the scene end in the generation kernel), of the ideal-culling event
+   counts of SURVEY.md section 8d (leaf tests, affine transforms, box tests, merged hits, shaded boundaries, light
+   terms); then the average duration (ms, HIP events on the render stream) and size (rays) of the k_visual
+   launches made since the previous call while option "time_kernels" was 1; then how many of the n rays reached
+   k_visual.  out9: 9 doubles. */
+int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out9);
 
 /* Tunables (no counterpart in the reference).  name: "hit_arena" (hits per ray, default 48),
-   "chunk_samples" (samples per wavefront pass), "bvh" (0/1: culling boxes), "time_kernels" (0/1). */
+   "chunk_samples" (samples per wavefront pass), "bvh" (0/1: culling boxes), "root_cull" (0/1: finish rays that miss
+   every box of the scene in the generation kernel), "time_kernels" (0/1). */
 int  rt_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus

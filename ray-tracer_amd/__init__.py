@@ -6,4 +6,5 @@ The directory name has a hyphen, so load this package with `rt_loader.load()` (r
 tests/conftest.py, which registers it as module `ray_tracer_amd`.
 """
 from . import binding  # noqa: F401
+from . import sharding  # noqa: F401
 from .binding import *  # noqa: F401,F403

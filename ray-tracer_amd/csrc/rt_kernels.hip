@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
  * Counts, for each ray, the events of the IDEAL-culling algorithm of SURVEY.md section 8d: a primitive is
  * tested only if the ray touches that primitive's own box; the box tests are those of a balanced hierarchy
  * over the leaves (2 per level on the way down plus 2 per leaf reached). */
-__global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, const double *org, const double *dir, unsigned long long *out /*6*/)
+__global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, const double *org, const double *dir, unsigned long long *out /*7*/)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
@@ -632,6 +632,8 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
     }
     unsigned levels = 0;
     while ((1u << levels) < nleaves) levels++;
+    /* only rays that reach k_visual count: the others ended in k_generate_cull */
+    if (!scene_may_hit(S, lds, ray, RT_INFINITY)) return;
     Arena A;
     int start;
     int count = intersect_scene<false>(S, lds, ray, RT_INFINITY, A, start);
@@ -641,6 +643,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
     atomicAdd(&out[3], (unsigned long long)(2 * leaf));
     atomicAdd(&out[4], (unsigned long long)(count > 0 ? 1 : 0));
     atomicAdd(&out[5], (unsigned long long)(count > 0 ? S.n_lights : 0));
+    atomicAdd(&out[6], 1ull);
 }
 
 /* ------------------------------------------------------------------ reconstruction

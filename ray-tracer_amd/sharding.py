@@ -1,0 +1,39 @@
+"""Row-band sharding of one frame over ranks: one process per GPU, each rank renders a
+contiguous band of output rows with its own halo of samples, rank 0 gathers the bands.  No collective on the
+data path other than that one gather per frame."""
+import ctypes as C
+
+
+def row_bands(height, world):
+    """Band boundaries: rank r renders rows [b[r], b[r+1])."""
+    return [(height * r) // world for r in range(world + 1)]
+
+
+def plan_rows(rt_lib, desc_cls, sampler, width, height, spp, row0, row1):
+    """rt_plan_rows (include/rt_amd.h): supersample rows and tile rows a band needs.  Host only."""
+    out = (C.c_int * 8)()
+    rd = desc_cls(width, height, float(spp), row0, row1)
+    rt_lib.rt_plan_rows.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    rc = rt_lib.rt_plan_rows(int(sampler), C.byref(rd), out)
+    if rc:
+        raise RuntimeError("rt_plan_rows failed: %d" % rc)
+    keys = ("src_y0", "src_y1", "tile_y0", "tiles_y", "nW", "nH", "tiles_x", "tiles_y_total")
+    return dict(zip(keys, list(out)))
+
+
+def gather_bands(planes, bands, rank, world, dist):
+    """planes: torch tensor [3][H][W] whose rows bands[rank]:bands[rank+1] this rank has rendered.  After the call
+    rank 0's planes holds every band.  One torch.distributed.gather (RCCL on GPUs, gloo on CPU) of equal-size slabs."""
+    import torch
+    if world == 1:
+        return planes
+    maxrows = max(bands[r + 1] - bands[r] for r in range(world))
+    row0, row1 = bands[rank], bands[rank + 1]
+    slab = torch.zeros((planes.shape[0], maxrows, planes.shape[2]), dtype=planes.dtype, device=planes.device)
+    slab[:, : row1 - row0, :] = planes[:, row0:row1, :]
+    out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+    dist.gather(slab, out, dst=0)
+    if rank == 0:
+        for r in range(world):
+            planes[:, bands[r]:bands[r + 1], :] = out[r][:, : bands[r + 1] - bands[r], :]
+    return planes

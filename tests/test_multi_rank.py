@@ -1,0 +1,87 @@
+"""Multi-rank path on CPU (gloo, world size 2 and 3): band arithmetic, halo planning and the one gather per frame.
+
+The GPU never enters here: each rank takes its band from an image rendered by the ORACLE (test infrastructure), so
+what is tested is the host logic bench.py and a multi-GPU caller use -- ray-tracer_amd/sharding.py and
+rt_plan_rows (include/rt_amd.h)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, height, width, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    ob = ge.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        raw = rt.FrontScene("S0", "test", optimize=False)
+        osc = ob.OracleScene(raw.desc)
+        rd = rt.RtRenderDesc(width, height, 1.0, 0, 0)
+        full, _, _ = osc.render(width, height, 1, rd, rt.RtStats(), threads=1)
+        bands = rt.sharding.row_bands(height, world)
+        mine = torch.zeros((3, height, width), dtype=torch.float32)
+        mine[:, bands[rank]:bands[rank + 1], :] = torch.from_numpy(full[:, bands[rank]:bands[rank + 1], :])
+        rt.sharding.gather_bands(mine, bands, rank, world, dist)
+        if rank == 0:
+            q.put(bool(np.array_equal(mine.numpy(), full)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 37), (3, 50)])
+def test_band_gather_gloo(world, height):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world * 7 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, height, 48, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_row_bands_partition():
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    for h in (1, 7, 2160, 2161):
+        for w in (1, 2, 3, 8):
+            b = rt.sharding.row_bands(h, w)
+            assert b[0] == 0 and b[-1] == h and all(b[i] <= b[i + 1] for i in range(w))
+
+
+@pytest.mark.parametrize("width,height,spp,world", [(64, 48, 4, 2), (96, 54, 16, 3), (80, 100, 9, 8)])
+def test_halo_covers_every_contributing_sample(rt, oracle, width, height, spp, world):
+    """Every sample whose bilinear splat touches a supersample row that the vertical filter reads for a band must
+    lie in the tile rows rt_plan_rows assigns to that band: then bands need no exchange."""
+    raw = rt.FrontScene("S0", "fastblue", optimize=False)
+    osc = oracle.OracleScene(raw.desc)
+    _, _, total = osc.samples(width, height, spp, 0, 0)
+    _, xy, _ = osc.samples(width, height, spp, 0, total)
+    L = rt.rt_lib()
+    whole = rt.sharding.plan_rows(L, rt.RtRenderDesc, rt.RT_SAMPLER_FASTBLUE, width, height, spp, 0, 0)
+    assert whole["tile_y0"] == 0 and whole["tiles_y"] == whole["tiles_y_total"]
+    assert total == whole["tiles_x"] * whole["tiles_y_total"] * 1600
+    bands = rt.sharding.row_bands(height, world)
+    # the reference's loop order is tile x outer, tile y inner (Sampling.cpp:498-499)
+    tile_y = (np.arange(total) // 1600) % whole["tiles_y_total"]
+    y = xy[:, 1]
+    for r in range(world):
+        if bands[r] == bands[r + 1]:
+            continue
+        p = rt.sharding.plan_rows(L, rt.RtRenderDesc, rt.RT_SAMPLER_FASTBLUE, width, height, spp, bands[r], bands[r + 1])
+        lo_row = np.floor(y - 0.5)             # a splat touches rows floor(y - 0.5) and the next (Image.cpp:1317-1330)
+        touches = (lo_row + 1 >= p["src_y0"]) & (lo_row <= p["src_y1"] - 1)
+        inside = (tile_y >= p["tile_y0"]) & (tile_y < p["tile_y0"] + p["tiles_y"])
+        assert not np.any(touches & ~inside), "band %d misses contributing samples" % r
