@@ -170,7 +170,7 @@ def cpu_baseline(ge, rt, scene):
     ob = ge.load_oracle()
     raw = rt.FrontScene(scene, "fastblue", optimize=False)
     osc = ob.OracleScene(raw.desc)
-    w, h, spp = (160, 90, 16) if scene == "S0" else (256, 144, 16)
+    w, h, spp = (512, 288, 16) if scene == "S0" else (640, 360, 16)     # about 15-25 s of single-thread work
     rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
     st = rt.RtStats()
     t0 = time.perf_counter()

@@ -194,7 +194,7 @@ def test_chunking_does_not_change_results(gpu):
     try:
         b, sb = g.render(64, 64, 4)
     finally:
-        gpu.rt_lib().rt_set_option(b"chunk_samples", 1 << 20)
+        gpu.rt_lib().rt_set_option(b"chunk_samples", 1 << 24)
     assert np.array_equal(a, b) and sa.rays() == sb.rays()
 
 
@@ -210,3 +210,47 @@ def test_full_size_properties_S0(gpu):
     nW, nH = int(1024 * 4 + 0.5), int(576 * 4 + 0.5)
     assert st.samples == ((nW + 39) // 40) * ((nH + 39) // 40) * 1600
     assert st.rays_primary == st.samples and st.hit_overflow == 0
+
+
+@pytest.mark.parametrize("scene,sampler,w,h,spp", [("S0", "fastblue", 320, 180, 4), ("S1", "fastblue", 96, 64, 4), (SCENE_CSG, "", 64, 64, 4),
+                                                   ("S2", "fastblue", 96, 64, 4)], ids=["S0", "S1", "csg", "S2"])
+def test_culling_never_changes_results(gpu, scene, sampler, w, h, spp):
+    """Conservative boxes, the union-region BVH with its tree-order fold, fused chains and the root cull are
+    evaluation strategy only: switching them off (every ray visits every node, like the reference) gives the same
+    image bit for bit and the same ray counts."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene(scene, sampler, optimize=True)
+    ref, sr = gpu.GpuScene(fs.desc).render(w, h, spp)
+    try:
+        L.rt_set_option(b"root_cull", 0)
+        a, sa = gpu.GpuScene(fs.desc).render(w, h, spp)
+        L.rt_set_option(b"bvh", 0)
+        b, sb = gpu.GpuScene(fs.desc).render(w, h, spp)
+    finally:
+        L.rt_set_option(b"root_cull", 1)
+        L.rt_set_option(b"bvh", 1)
+    assert np.array_equal(ref, a) and np.array_equal(ref, b)
+    assert sr.rays() == sa.rays() == sb.rays() and sr.rays_shadow == sb.rays_shadow and sr.rays_secondary == sb.rays_secondary
+
+
+def test_baseline_size_properties_S0_4k_64spp(gpu):
+    """BASELINE configs[1] (3840x2160, 64 spp): too large for the oracle, so size-independent properties --
+    sample-count formula, one ray per sample, determinism, finiteness, and a row band rendered on its own (the
+    multi-GPU path) equal to the same rows of the full frame."""
+    import torch
+    fs = gpu.FrontScene("S0", "fastblue", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    W, H = 3840, 2160
+    a = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    st = g.render_device(W, H, 64, a.data_ptr(), 0)
+    g.render_device(W, H, 64, b.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert st.samples == 768 * 432 * 1600 == 530841600
+    assert st.rays_primary == st.samples and st.rays_shadow == 0 and st.rays_secondary == 0 and st.hit_overflow == 0
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert float(a.sum()) > 0.0
+    c = torch.zeros_like(a)
+    g.render_device(W, H, 64, c.data_ptr(), 0, 1080, 1350)
+    torch.cuda.synchronize()
+    assert torch.equal(c[:, 1080:1350, :], a[:, 1080:1350, :])
