@@ -230,7 +230,9 @@ struct Work {
 #define WR(w, i) (w).r[(i) + 1]
 #define WN(w, i) (w).n[(i) + 1]
 
-RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; for (int i = 0; i < 6; i++) { w.r[i] = 0.0; w.n[i] = d3(0, 0, 0); } }
+/* roots and normals are always written before they are read (a slot HitList reads is a root the solver stored or the
+   synthetic hit it has just set), so only the scalars are initialised: the arrays live in private memory */
+RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; }
 
 /* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
 __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
@@ -652,7 +654,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     RegionFrame rf[RT_MAX_REGION_DEPTH];
     int nrf = 0;
     int depth = 0;
-    rs[0] = wray;
+    DRay cur = wray;            /* the ray in the current frame; rs[] holds the enclosing frames' rays (touched only by non-chain affines) */
 #ifdef RT_PHASE_PROF
     long long t_cr = clock64();
 #endif
@@ -676,26 +678,28 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             if (!cull_box_hit(S.boxes[in.a].lo, S.boxes[in.a].hi, cr)) pc = in.b;
             break;
         case OP_REFBOX:
-            if (!extent_test(S.boxes[in.a].lo, S.boxes[in.a].hi, rs[depth])) pc = in.b;
+            if (!extent_test(S.boxes[in.a].lo, S.boxes[in.a].hi, cur)) pc = in.b;
             break;
         case OP_PUSH_AFFINE: {                                  /* AffineSolid::Intersect, Solids.cpp:899-913 */
             const RtAffine &a = S.affines[in.a];
             DRay nr;
-            nr.dir = mat_vec(a.minv, rs[depth].dir);
-            nr.org = mat_vec(a.minv, rs[depth].org - d3(a.tr[0], a.tr[1], a.tr[2]));
+            nr.dir = mat_vec(a.minv, cur.dir);
+            nr.org = mat_vec(a.minv, cur.org - d3(a.tr[0], a.tr[1], a.tr[2]));
+            rs[depth] = cur;
             depth++;
-            rs[depth] = nr;
+            cur = nr;
             break;
         }
         case OP_POP_AFFINE:
             depth--;
+            cur = rs[depth];
             break;
-        case OP_QUADRIC: { PROF_BEGIN(tp); quadric_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
-        case OP_POLY:    { PROF_BEGIN(tp); poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
-        case OP_SLAB:    { PROF_BEGIN(tp); slab_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_QUADRIC: { PROF_BEGIN(tp); quadric_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_POLY:    { PROF_BEGIN(tp); poly_hits(S.prims[in.a], (uint16_t)in.a, S.planes, cur, A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_SLAB:    { PROF_BEGIN(tp); slab_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_TORUS:
             if constexpr (LITE) { A.bail = 1; goto done; }
-            else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, rs[depth], A, in.tag); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
@@ -767,7 +771,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             PROF_BEGIN(tc);
             const RtChain &ch = S.chains[in.a];
             if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b) goto region_ret; break; }
-            DRay r = rs[depth];
+            DRay r = cur;
             for (int k = 0; k < ch.n_affine; k++) {                 /* AffineSolid::Intersect, Solids.cpp:899-913 */
                 const RtAffine &a = S.affines[ch.affine[k]];
                 DRay nr;
@@ -852,8 +856,8 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             const RtClip &c = S.clips[in.a];
             Work w;
             work_init(w);
-            clip_plane(rs[depth], d3(c.cv1[0], c.cv1[1], c.cv1[2]), w, 0, 0.0);
-            clip_plane(rs[depth], d3(c.cv2[0], c.cv2[1], c.cv2[2]), w, 1, 0.0);
+            clip_plane(cur, d3(c.cv1[0], c.cv1[1], c.cv1[2]), w, 0, 0.0);
+            clip_plane(cur, d3(c.cv2[0], c.cv2[1], c.cv2[2]), w, 1, 0.0);
             int before = A.nlist;
             hit_list(w, A, 2 * in.b + 1, (uint16_t)(0x8000 | in.a), c.leaf_affine);
             if (A.nlist > before) merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
