@@ -276,6 +276,57 @@ __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_aff
     A.top += nout;
 }
 
+/* HitList for solvers that return at most two roots (quadrics, polyhedra, slabs): the same rules as hit_list
+   above, written without variable array indices so that the roots and normals stay in registers.
+   The list is (optional synthetic t = 0 hit) + (roots >= 0), at most three entries. */
+__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
+{
+    const int count = w.count;
+    const double r0 = WR(w, 0), r1 = WR(w, 1);
+    int first = 0;
+    if (count > 0 && !(r0 >= 0.0)) first = (count > 1 && !(r1 >= 0.0)) ? 2 : 1;
+    const int m = count - first;                                /* roots kept: 0, 1 or 2 */
+    const int origin_inside = (first & 1) ^ w.inside_inf;
+    const double ta = (first == 0) ? r0 : r1;                   /* first kept root (m >= 1) */
+    const D3 na = (first == 0) ? WN(w, 0) : WN(w, 1);
+    const bool far_first = (count == 0) || (m == 0) || (ta > w.eps);        /* Q10 */
+    const bool prepend = origin_inside && far_first;
+    double t0, t1, t2 = r1;
+    D3 n0, n1, n2 = WN(w, 1);
+    int L;
+    if (prepend) { t0 = 0.0; n0 = d3(0.0, 0.0, 0.0); t1 = ta; n1 = na; L = m + 1; }
+    else { t0 = ta; n0 = na; t1 = r1; n1 = WN(w, 1); L = m; }
+    if (L >= 2 && t0 == 0.0 && t1 < w.eps) { t0 = t2; n0 = n2; L -= 2; }
+    else if (L >= 1 && t0 < w.eps) { t0 = 0.0; n0 = d3(0.0, 0.0, 0.0); }
+    if (L <= 0) return;
+    if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
+    /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
+    const int last_in = w.inside_inf ? 1 : 0;
+    {
+        HitRec &h = A.h[A.top];
+        h.t = t0; h.n = n0; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.mat = (uint16_t)(((L - 1) & 1) ? !last_in : last_in);
+        h.surf = (t0 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+    }
+    if (L >= 2) {
+        HitRec &h = A.h[A.top + 1];
+        h.t = t1; h.n = n1; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.mat = (uint16_t)(((L - 2) & 1) ? !last_in : last_in);
+        h.surf = (t1 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+    }
+    if (L >= 3) {
+        HitRec &h = A.h[A.top + 2];
+        h.t = t2; h.n = n2; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.mat = (uint16_t)last_in;
+        h.surf = (t2 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+    }
+    A.l_start[A.nlist] = (uint16_t)A.top;
+    A.l_count[A.nlist] = (uint16_t)L;
+    A.l_tag[A.nlist] = tag;
+    A.nlist++;
+    A.top += L;
+}
+
 /* ClipPlane, Solids.cpp:232-273 */
 RT_DEV int clip_plane(const DRay &ray, const D3 &nrm, Work &w, int do_clip, double pn)
 {
@@ -382,17 +433,15 @@ __device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Ar
     double b = 2.0 * (d.x * o.x + d.y * o.y + d.z * o.z * P) + d.z * Q;
     double c = o.x * o.x + o.y * o.y + o.z * o.z * P + o.z * Q + R;
     w.count = solve_quadratic(&WR(w, 0), a, b, c);
-    for (int i = 0; i < w.count; i++) {
-        D3 p = ray_at(ray, WR(w, i));
-        WN(w, i) = d3(p.x, p.y, p.z * P + 0.5 * Q);
-    }
+    if (w.count > 0) { D3 p = ray_at(ray, WR(w, 0)); WN(w, 0) = d3(p.x, p.y, p.z * P + 0.5 * Q); }
+    if (w.count > 1) { D3 p = ray_at(ray, WR(w, 1)); WN(w, 1) = d3(p.x, p.y, p.z * P + 0.5 * Q); }
     if (q.i0 == 1) {
         clip_plane(ray, d3(0.0, 0.0, 1.0), w, 1, 1.0);
         clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
     }
     if (q.i0 == -1) { a = -a; b = -b; c = -c; }
     w.inside_inf = (a < 0.0) ? 1 : 0;
-    hit_list(w, A, tag, prim, q.leaf_affine);
+    hit_list2(w, A, tag, prim, q.leaf_affine);
 }
 
 __device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag)   /* Solids.cpp:769-781 */
@@ -403,7 +452,7 @@ __device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, 
     int n = clip_plane(ray, d3(pl[0], pl[1], pl[2]), w, 0, 1.0);
     for (int i = 1; n && i < p.i0; i++)
         n = clip_plane(ray, d3(pl[3 * i], pl[3 * i + 1], pl[3 * i + 2]), w, 1, 1.0);
-    hit_list(w, A, tag, prim, p.leaf_affine);
+    hit_list2(w, A, tag, prim, p.leaf_affine);
 }
 
 __device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag)        /* Solids.cpp:859-869 */
@@ -412,7 +461,7 @@ __device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena
     work_init(w);
     int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
     if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
-    hit_list(w, A, tag, prim, p.leaf_affine);
+    hit_list2(w, A, tag, prim, p.leaf_affine);
 }
 
 RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
@@ -859,7 +908,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             clip_plane(cur, d3(c.cv1[0], c.cv1[1], c.cv1[2]), w, 0, 0.0);
             clip_plane(cur, d3(c.cv2[0], c.cv2[1], c.cv2[2]), w, 1, 0.0);
             int before = A.nlist;
-            hit_list(w, A, 2 * in.b + 1, (uint16_t)(0x8000 | in.a), c.leaf_affine);
+            hit_list2(w, A, 2 * in.b + 1, (uint16_t)(0x8000 | in.a), c.leaf_affine);
             if (A.nlist > before) merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
             else {
                 /* Merge(body, empty): every body hit is still filtered through op(pmLeft, vacuum) */
