@@ -243,34 +243,66 @@ struct Flattener {
             else kids.push_back(c);
         }
     }
-    /* sort idx[a,b) along the longest axis of its bound and return the median position */
-    int split_range(std::vector<int> &idx, int a, int b, const std::vector<Box> &boxes)
+    static double half_area(const Box &b)
+    {
+        if (b.empty) return 0.0;
+        double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    }
+    /* split idx[a,b) (b - a >= 2) in two: surface-area heuristic over all positions on all three axes (the regions
+       here hold hundreds of children, not millions), or the median of the longest axis when sah is off */
+    int split_range(std::vector<int> &idx, int a, int b, const std::vector<Box> &boxes, bool sah)
     {
         Box all;
         for (int k = a; k < b; k++) all = box_union(all, boxes[idx[k]]);
         int axis = 0;
         for (int d = 1; d < 3; d++) if (all.hi[d] - all.lo[d] > all.hi[axis] - all.lo[axis]) axis = d;
-        std::sort(idx.begin() + a, idx.begin() + b, [&](int x, int y) {
-            return boxes[x].lo[axis] + boxes[x].hi[axis] < boxes[y].lo[axis] + boxes[y].hi[axis]; });
-        return (a + b) / 2;
+        auto sort_axis = [&](int ax) {
+            std::sort(idx.begin() + a, idx.begin() + b, [&](int x, int y) {
+                double cx = boxes[x].lo[ax] + boxes[x].hi[ax], cy = boxes[y].lo[ax] + boxes[y].hi[ax];
+                return cx < cy || (cx == cy && x < y); });
+        };
+        int n = b - a, best_axis = axis, best_pos = (a + b) / 2;
+        if (sah && n > 2) {
+            double best = 1e300;
+            std::vector<double> right(n);
+            for (int ax = 0; ax < 3; ax++) {
+                sort_axis(ax);
+                Box acc;
+                for (int k = n - 1; k > 0; --k) { acc = box_union(acc, boxes[idx[a + k]]); right[k] = half_area(acc); }
+                acc = Box();
+                for (int k = 1; k < n; k++) {
+                    acc = box_union(acc, boxes[idx[a + k - 1]]);
+                    double cost = half_area(acc) * k + right[k] * (n - k);
+                    if (cost < best) { best = cost; best_axis = ax; best_pos = a + k; }
+                }
+            }
+        }
+        sort_axis(best_axis);
+        return best_pos;
     }
-    /* 4-wide BVH over idx[a,b) (b - a >= 1): two levels of median splits per node; nodes are numbered breadth
-       first so that the top of the tree is what lands in LDS */
-    int build_bvh(std::vector<int> &idx, int a0, int b0, const std::vector<Box> &boxes)
+    /* 4-wide BVH over idx[a0,b0) (>= 1 entries): two levels of binary splits per node; nodes are numbered breadth
+       first so that the top of the tree is what lands in LDS.  Returns the root and the tree depth. */
+    int build_bvh_once(std::vector<int> &idx, int a0, int b0, const std::vector<Box> &boxes, bool sah, int &depth_out)
     {
-        struct Job { int node, a, b; };
+        struct Job { int node, a, b, depth; };
         std::vector<Job> queue;
         int root = (int)o.bvh.size();
         o.bvh.push_back(RtBvhNode());
-        queue.push_back(Job{ root, a0, b0 });
+        queue.push_back(Job{ root, a0, b0, 1 });
+        depth_out = 1;
         for (size_t q = 0; q < queue.size(); q++) {
             Job j = queue[q];
+            if (j.depth > depth_out) depth_out = j.depth;
             int cuts[5], nc = 0;
             if (j.b - j.a <= 4) { for (int k = j.a; k <= j.b; k++) cuts[nc++] = k; }
             else {
-                int m = split_range(idx, j.a, j.b, boxes);
-                int l = split_range(idx, j.a, m, boxes), r = split_range(idx, m, j.b, boxes);
-                cuts[0] = j.a; cuts[1] = l; cuts[2] = m; cuts[3] = r; cuts[4] = j.b; nc = 5;
+                int m = split_range(idx, j.a, j.b, boxes, sah);
+                cuts[nc++] = j.a;
+                if (m - j.a >= 2) cuts[nc++] = split_range(idx, j.a, m, boxes, sah);
+                cuts[nc++] = m;
+                if (j.b - m >= 2) cuts[nc++] = split_range(idx, m, j.b, boxes, sah);
+                cuts[nc++] = j.b;
             }
             RtBvhNode node;
             memset(&node, 0, sizeof node);
@@ -289,10 +321,21 @@ struct Flattener {
                 else {
                     node.child[c] = (int)o.bvh.size();
                     o.bvh.push_back(RtBvhNode());
-                    queue.push_back(Job{ node.child[c], a, b });
+                    queue.push_back(Job{ node.child[c], a, b, j.depth + 1 });
                 }
             }
             o.bvh[j.node] = node;
+        }
+        return root;
+    }
+    int build_bvh(std::vector<int> &idx, int a0, int b0, const std::vector<Box> &boxes)
+    {
+        size_t mark = o.bvh.size();
+        int depth = 0;
+        int root = build_bvh_once(idx, a0, b0, boxes, true, depth);
+        if (3 * depth + 1 > RT_BVH_STACK) {         /* too unbalanced for the traversal stack: fall back to median splits */
+            o.bvh.resize(mark);
+            root = build_bvh_once(idx, a0, b0, boxes, false, depth);
         }
         return root;
     }
