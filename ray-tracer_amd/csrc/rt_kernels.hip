@@ -38,10 +38,14 @@ __device__ int wave_alloc(int count, int *counter)
     return base + incl - count;
 }
 
-RT_DEV void spec_store(float *base, size_t cap, size_t idx, const Spec &s) { for (int k = 0; k < RT_NSPEC; k++) base[(size_t)k * cap + idx] = s.v[k]; }
-RT_DEV Spec spec_fetch(const float *base, size_t cap, size_t idx) { Spec s; for (int k = 0; k < RT_NSPEC; k++) s.v[k] = base[(size_t)k * cap + idx]; return s; }
-RT_DEV void d3_store(double *base, size_t cap, int field, size_t idx, const D3 &v) { base[(size_t)field * cap + idx] = v.x; base[(size_t)(field + 1) * cap + idx] = v.y; base[(size_t)(field + 2) * cap + idx] = v.z; }
-RT_DEV D3 d3_fetch(const double *base, size_t cap, int field, size_t idx) { return d3(base[(size_t)field * cap + idx], base[(size_t)(field + 1) * cap + idx], base[(size_t)(field + 2) * cap + idx]); }
+/* Frame and queue arrays are streamed: written once by one kernel, read once by the next.  Non-temporal accesses
+   keep them from displacing the per-lane private memory (hit arenas) that the tracing kernels re-use from L2. */
+template <typename T> RT_DEV void nt_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+template <typename T> RT_DEV T nt_load(const T *p) { return __builtin_nontemporal_load(p); }
+RT_DEV void spec_store(float *base, size_t cap, size_t idx, const Spec &s) { for (int k = 0; k < RT_NSPEC; k++) nt_store(&base[(size_t)k * cap + idx], s.v[k]); }
+RT_DEV Spec spec_fetch(const float *base, size_t cap, size_t idx) { Spec s; for (int k = 0; k < RT_NSPEC; k++) s.v[k] = nt_load(&base[(size_t)k * cap + idx]); return s; }
+RT_DEV void d3_store(double *base, size_t cap, int field, size_t idx, const D3 &v) { nt_store(&base[(size_t)field * cap + idx], v.x); nt_store(&base[(size_t)(field + 1) * cap + idx], v.y); nt_store(&base[(size_t)(field + 2) * cap + idx], v.z); }
+RT_DEV D3 d3_fetch(const double *base, size_t cap, int field, size_t idx) { return d3(nt_load(&base[(size_t)field * cap + idx]), nt_load(&base[(size_t)(field + 1) * cap + idx]), nt_load(&base[(size_t)(field + 2) * cap + idx])); }
 
 /* ------------------------------------------------------------------ sample generation + camera */
 __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s, double *pos2, double *v2, double *aux)
