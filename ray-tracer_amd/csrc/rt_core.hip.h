@@ -569,16 +569,14 @@ RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.l_start[A.nlist]; }
 /* ================================================================== the per-ray stack machine
  * Evaluates psModel->Intersect(ray) (RayTracer2020.h:72): returns the hit list as [start, start+count)
  * in the arena.  tmax bounds the culling tests only (shadow rays stop at t = 1, Shade.cpp:328). */
-struct RegionFrame {
-    int      region, ncand, pos, base_lists, nl_before, out_tag;
-    uint16_t cand[RT_MAX_CAND];
-};
+/* the innermost union region being folded lives in registers; enclosing ones are saved in private memory */
+struct RegionCur { int ncand, pos, base_lists, nl_before, out_tag, child_pc0, lca0, nchild, uid, end_pc, cur_c; };
 
 /* min of lca[a .. b-1], a < b (RtRegion sparse table) */
-RT_DEV int region_gap(const RtDevScene &S, const RtRegion &rg, int a, int b)
+RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
 {
     int len = b - a, l = 31 - __clz(len);
-    const int32_t *row = S.region_lca + rg.lca0 + (size_t)l * rg.n_children;
+    const int32_t *row = S.region_lca + rg.lca0 + (size_t)l * rg.nchild;
     int x = row[a], y = row[b - (1 << l)];
     return x < y ? x : y;
 }
@@ -700,7 +698,8 @@ template <bool LITE>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
-    RegionFrame rf[RT_MAX_REGION_DEPTH];
+    RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, saved[RT_MAX_REGION_DEPTH];
+    uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
     int nrf = 0;
     int depth = 0;
     DRay cur = wray;            /* the ray in the current frame; rs[] holds the enclosing frames' rays (touched only by non-chain affines) */
@@ -802,18 +801,21 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             if (!top_is(A, 2 * in.a)) pc = in.b;
             break;
         case OP_REGION: {
-            const RtRegion &rg = S.regions[in.a];
+            const RtRegion rg = S.regions[in.a];
             if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow = 1; pc = rg.end_pc; break; }
-            RegionFrame &f = rf[nrf];
+            uint16_t *cd = cands[nrf];
             int ov = 0;
             PROF_BEGIN(tb);
-            f.ncand = region_candidates(S, L, rg, cr, f.cand, ov);
+            const int nc = region_candidates(S, L, rg, cr, cd, ov);
             PROF_END(A, 1, tb);
             if (ov) A.overflow = 1;
-            if (f.ncand == 0) { pc = rg.end_pc; break; }
-            f.region = in.a; f.pos = 0; f.base_lists = A.nlist; f.nl_before = A.nlist; f.out_tag = in.tag;
+            if (nc == 0) { pc = rg.end_pc; break; }
+            if (nrf > 0) saved[nrf - 1] = cf;
+            cf.ncand = nc; cf.pos = 0; cf.base_lists = A.nlist; cf.nl_before = A.nlist; cf.out_tag = in.tag;
+            cf.child_pc0 = rg.child_pc0; cf.lca0 = rg.lca0; cf.nchild = rg.n_children; cf.uid = rg.uid; cf.end_pc = rg.end_pc;
+            cf.cur_c = cd[0];
             nrf++;
-            pc = S.region_child_pc[rg.child_pc0 + f.cand[0]];
+            pc = S.region_child_pc[cf.child_pc0 + cf.cur_c];
             break;
         }
         case OP_CHAIN: {
@@ -875,27 +877,27 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         region_ret: {
             PROF_BEGIN(tr);
             /* one region child done: fold the non-empty lists in the union tree's own order */
-            RegionFrame &f = rf[nrf - 1];
-            const RtRegion &rg = S.regions[f.region];
-            const int ctag = 2 * rg.uid;
-            int c = f.cand[f.pos];
-            if (A.nlist > f.nl_before) {            /* the child left a list on top */
+            const int ctag = 2 * cf.uid;
+            const int c = cf.cur_c;
+            if (A.nlist > cf.nl_before) {           /* the child left a list on top */
                 int e = A.nlist - 1;
                 A.l_idx[e] = (uint16_t)c;
-                A.l_gap[e] = (e > f.base_lists) ? region_gap(S, rg, A.l_idx[e - 1], c) : -1;
+                A.l_gap[e] = (e > cf.base_lists) ? region_gap(S, cf, A.l_idx[e - 1], c) : -1;
             }
-            f.pos++;
-            if (f.pos < f.ncand) {
-                int next = f.cand[f.pos];
-                while (A.nlist - f.base_lists >= 2 && A.l_gap[A.nlist - 1] > region_gap(S, rg, A.l_idx[A.nlist - 1], next))
+            cf.pos++;
+            if (cf.pos < cf.ncand) {
+                const int next = cands[nrf - 1][cf.pos];
+                while (A.nlist - cf.base_lists >= 2 && A.l_gap[A.nlist - 1] > region_gap(S, cf, A.l_idx[A.nlist - 1], next))
                     merge_top(A, MERGE_MAX, S.mats, ctag);
-                f.nl_before = A.nlist;
-                pc = S.region_child_pc[rg.child_pc0 + next];
+                cf.nl_before = A.nlist;
+                cf.cur_c = next;
+                pc = S.region_child_pc[cf.child_pc0 + next];
             } else {
-                while (A.nlist - f.base_lists >= 2) merge_top(A, MERGE_MAX, S.mats, ctag);
-                if (A.nlist - f.base_lists == 1) A.l_tag[A.nlist - 1] = f.out_tag;
+                while (A.nlist - cf.base_lists >= 2) merge_top(A, MERGE_MAX, S.mats, ctag);
+                if (A.nlist - cf.base_lists == 1) A.l_tag[A.nlist - 1] = cf.out_tag;
                 nrf--;
-                pc = rg.end_pc;
+                pc = cf.end_pc;
+                if (nrf > 0) cf = saved[nrf - 1];
             }
             PROF_END(A, 6, tr);
             break;
