@@ -187,7 +187,7 @@ __device__ int solve_quartic(double *r, double a, double b, double c, double d, 
 }
 
 /* ================================================================== per-ray hit storage */
-struct HitRec {
+struct __attribute__((aligned(16))) HitRec {
     double   t;
     D3       n;
     uint32_t leaf_affine;   /* index + 1, 0 = none */
@@ -234,6 +234,8 @@ struct Work {
    synthetic hit it has just set), so only the scalars are initialised: the arrays live in private memory */
 RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; }
 
+__device__ void arena_compact(Arena &A);
+
 /* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
 __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
 {
@@ -255,6 +257,7 @@ __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_aff
     }
     int nout = w.count - first;
     if (nout <= 0) return;
+    if (A.top + nout > RT_ARENA) arena_compact(A);
     if (A.top + nout > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     int inside = w.inside_inf;
@@ -299,6 +302,7 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
     if (L >= 2 && t0 == 0.0 && t1 < w.eps) { t0 = t2; n0 = n2; L -= 2; }
     else if (L >= 1 && t0 < w.eps) { t0 = 0.0; n0 = d3(0.0, 0.0, 0.0); }
     if (L <= 0) return;
+    if (A.top + L > RT_ARENA) arena_compact(A);
     if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     const int last_in = w.inside_inf ? 1 : 0;
@@ -522,11 +526,28 @@ RT_DEV uint16_t mat_op(int op, uint16_t l, uint16_t r, const RtMaterialDev *mats
     return dr <= 0.0 ? l : (uint16_t)0;
 }
 
-/* merge the two top lists (left below right, contiguous) into one at the left list's place */
+/* Lists sit in the arena in stack order with increasing start offsets; a merge writes its result above both
+   operands and leaves it there (no copy back), so dead records can lie between live lists.  When space runs out
+   the live lists are packed down. */
+__device__ void arena_compact(Arena &A)
+{
+    int top = 0;
+    for (int l = 0; l < A.nlist; l++) {
+        const int s0 = A.l_start[l], c = A.l_count[l];
+        if (s0 != top) for (int i = 0; i < c; i++) A.h[top + i] = A.h[s0 + i];
+        A.l_start[l] = (uint16_t)top;
+        top += c;
+    }
+    A.top = top;
+}
+
+/* merge the two top lists (left below right) into one that takes the left list's place on the list stack */
 __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
 {
     int li = A.nlist - 2, ri = A.nlist - 1;
-    int ls = A.l_start[li], lc = A.l_count[li], rs = A.l_start[ri], rc = A.l_count[ri];
+    int lc = A.l_count[li], rc = A.l_count[ri];
+    if (A.top + lc + rc > RT_ARENA) arena_compact(A);
+    int ls = A.l_start[li], rs = A.l_start[ri];
     int out = A.top, nout = 0;
     if (out + lc + rc > RT_ARENA) { A.overflow = 1; A.nlist -= 1; A.l_tag[li] = tag; A.top = rs; return; }
     int il = 0, ir = 0;
@@ -550,15 +571,14 @@ __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
         }
     }
     if (nout == 1 && A.h[out].t == 0.0 && mats[A.h[out].mat].density == 0.0) nout = 0;     /* Solids.cpp:1053-1056 */
-    for (int i = 0; i < nout; i++) A.h[ls + i] = A.h[out + i];
     A.nlist -= 2;
     A.top = ls;
     if (nout > 0) {
         /* the merged entry keeps the left operand's l_gap and takes the right operand's l_idx */
-        A.l_start[A.nlist] = (uint16_t)ls; A.l_count[A.nlist] = (uint16_t)nout; A.l_tag[A.nlist] = tag;
+        A.l_start[A.nlist] = (uint16_t)out; A.l_count[A.nlist] = (uint16_t)nout; A.l_tag[A.nlist] = tag;
         A.l_idx[A.nlist] = A.l_idx[A.nlist + 1];
         A.nlist++;
-        A.top = ls + nout;
+        A.top = out + nout;
     }
 }
 
