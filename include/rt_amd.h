@@ -90,9 +90,10 @@ void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);
    k_visual.  out9: 9 doubles. */
 int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out9);
 
-/* Tunables (no counterpart in the reference).  name: "hit_arena" (hits per ray, default 48),
-   "chunk_samples" (samples per wavefront pass), "bvh" (0/1: culling boxes), "root_cull" (0/1: finish rays that miss
-   every box of the scene in the generation kernel), "time_kernels" (0/1). */
+/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 2^24),
+   "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
+   "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
+   "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */
 int  rt_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -70,3 +70,26 @@ SCENE_CSG = """(scene
  (pointlight -10 -10 -10 (scale (blackbody 6500) 500))
  (camera stereographic 0 0 9 70)
  (sampler fastblue))"""
+
+
+# thirteen disjoint spheres in a row along the view axis, distinct densities: rays down the axis collect 26 hits, so the
+# hit arena fills up, merges pile dead records under live lists and the arena must be compacted
+SCENE_ROW = """(scene
+ (model (makeunion
+     (translate 0 0 -0 (scale 0.3 0.3 0.3 (material 0.3 auto g_sRed plastic none none (sphere))))
+     (translate 0 0 -1 (scale 0.3 0.3 0.3 (material 0.35 auto g_sGreen plastic none none (sphere))))
+     (translate 0 0 -2 (scale 0.3 0.3 0.3 (material 0.4 auto g_sYellow plastic none none (sphere))))
+     (translate 0 0 -3 (scale 0.3 0.3 0.3 (material 0.45 auto g_sCyan plastic none none (sphere))))
+     (translate 0 0 -4 (scale 0.3 0.3 0.3 (material 0.5 auto g_sOrange plastic none none (sphere))))
+     (translate 0 0 -5 (scale 0.3 0.3 0.3 (material 0.55 auto g_sMagenta plastic none none (sphere))))
+     (translate 0 0 -6 (scale 0.3 0.3 0.3 (material 0.6 auto g_sWhite plastic none none (sphere))))
+     (translate 0 0 -7 (scale 0.3 0.3 0.3 (material 0.65 auto g_sRed plastic none none (sphere))))
+     (translate 0 0 -8 (scale 0.3 0.3 0.3 (material 0.7 auto g_sGreen plastic none none (sphere))))
+     (translate 0 0 -9 (scale 0.3 0.3 0.3 (material 0.75 auto g_sYellow plastic none none (sphere))))
+     (translate 0 0 -10 (scale 0.3 0.3 0.3 (material 0.8 auto g_sCyan plastic none none (sphere))))
+     (translate 0 0 -11 (scale 0.3 0.3 0.3 (material 0.85 auto g_sOrange plastic none none (sphere))))
+     (translate 0 0 -12 (scale 0.3 0.3 0.3 (material 0.9 auto g_sMagenta plastic none none (sphere))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 500))
+ (camera stereographic 0 0 9 70)
+ (sampler fastblue))"""

@@ -11,7 +11,7 @@ Bars:
 import numpy as np
 import pytest
 
-from conftest import SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
+from conftest import SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
 
 pytestmark = pytest.mark.gpu
 
@@ -254,3 +254,18 @@ def test_baseline_size_properties_S0_4k_64spp(gpu):
     g.render_device(W, H, 64, c.data_ptr(), 0, 1080, 1350)
     torch.cuda.synchronize()
     assert torch.equal(c[:, 1080:1350, :], a[:, 1080:1350, :])
+
+
+def test_long_hit_lists_compact_the_arena(gpu, oracle):
+    """26 hits per ray: the arena (64 records) only suffices because dead records left by merges are compacted."""
+    opt, raw, g, o = _pair(gpu, oracle, SCENE_ROW, "")
+    rng = np.random.default_rng(3)
+    n = 4000
+    org = np.concatenate([rng.uniform(-0.25, 0.25, (n, 2)), np.full((n, 1), 8.0)], axis=1)
+    dr = np.concatenate([rng.uniform(-0.01, 0.01, (n, 2)), -np.ones((n, 1))], axis=1)
+    gc, gt, gn, gl, gm, gs = g.intersect(org, dr, max_hits=32)
+    oc, ot, on, ol, om, osf = o.intersect(org, dr, max_hits=32)
+    assert oc.max() == 26 and (oc >= 20).mean() > 0.3
+    assert np.array_equal(gc, oc) and np.array_equal(gl, ol) and np.array_equal(gm, om) and np.array_equal(gs, osf)
+    assert np.array_equal(gt, ot) and np.array_equal(gn, on)
+    assert np.array_equal(g.radiance(org, dr), o.radiance(org, dr))
