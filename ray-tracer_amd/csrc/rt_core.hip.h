@@ -394,6 +394,14 @@ RT_DEV int extent_test(const double *lo, const double *hi, const DRay &ray)
    fused multiply-adds (the reference path is compiled with contraction off): per bound t = fma(b, inv, -o*inv).
    Rounding: -o*inv carries |o*inv| * 2^-53, the fma another half ulp of t; `slack` covers both. */
 struct CullRay { double o[3], inv[3], noi[3], tmax, slack; int zmask, neg; };
+/* reciprocal good to a few ulps (hardware estimate + two Newton steps): culling only, never the reference's arithmetic */
+RT_DEV double cull_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+}
 RT_DEV CullRay cull_ray(const DRay &r, double tmax)
 {
     CullRay c;
@@ -402,16 +410,18 @@ RT_DEV CullRay cull_ray(const DRay &r, double tmax)
     c.zmask = 0; c.neg = 0;
     c.slack = 0.0;
     for (int i = 0; i < 3; i++) {
-        if (d[i] != 0.0) { c.inv[i] = 1.0 / d[i]; c.noi[i] = -(c.o[i] * c.inv[i]); c.slack += fabs(c.noi[i]); if (d[i] < 0.0) c.neg |= 1 << i; }
+        /* directions too small to invert safely are treated like zero: the slab test then only asks whether the
+           origin lies between the planes, which is conservative for |t * d| far below the box padding */
+        if (fabs(d[i]) > 1.0e-280) { c.inv[i] = cull_rcp(d[i]); c.noi[i] = -(c.o[i] * c.inv[i]); c.slack += fabs(c.noi[i]); if (d[i] < 0.0) c.neg |= 1 << i; }
         else { c.inv[i] = 0.0; c.noi[i] = 0.0; c.zmask |= 1 << i; }
     }
-    c.slack *= 1.0e-15;
+    c.slack *= 1.0e-12;
     c.tmax = tmax;
     return c;
 }
 RT_DEV bool cull_interval_ok(double t0, double t1, const CullRay &c)
 {
-    return t0 - t1 <= c.slack + (fabs(t0) + fabs(t1)) * 1.0e-15;
+    return t0 - t1 <= c.slack + (fabs(t0) + fabs(t1)) * 1.0e-12;
 }
 RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
 {

@@ -60,9 +60,10 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
         return;
     }
     /* FastBlueSamplingTile::Render, Sampling.cpp:498-517: tile x outer, tile y inner, i innermost */
-    int64_t tile = s / RT_BLUE_N;
-    int i = (int)(s % RT_BLUE_N);
-    int tx = (int)(tile / g.tiles_y_local), ty = (int)(tile % g.tiles_y_local) + g.tile_y0;
+    const uint32_t tile = (uint32_t)(s / RT_BLUE_N);      /* < 2^31 tiles (checked by the host) */
+    int i = (int)(s - (int64_t)tile * RT_BLUE_N);
+    const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+    int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
     double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
     double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + vtx, vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + vty;
     pos2[0] = vx; pos2[1] = vy;
@@ -112,6 +113,41 @@ RT_DEV void root_ray(const RtDevScene &S, const RtSampleGrid &g, int64_t first, 
         r = camera_emit(S.cam, v[0], v[1], aux[0], aux[1]);     /* CastFunction, RayTracer2020.cpp:20-31 */
     }
 }
+/* The same ray to within ~1e-13 relative, with the divisions of the sample position and of Camera::Emit replaced
+   by multiplications with refined reciprocals: ONLY for the conservative cull in k_generate_cull (the culling boxes
+   are padded by 1e-6 relative + 1e-9 absolute, orders above this error); survivors get the exact ray. */
+RT_DEV DRay root_ray_for_cull(const RtDevScene &S, const RtSampleGrid &g, int64_t first, int k, const double *rays_org, const double *rays_dir)
+{
+    DRay r;
+    if (rays_org) {
+        r.org = d3(rays_org[3 * k], rays_org[3 * k + 1], rays_org[3 * k + 2]);
+        r.dir = d3(rays_dir[3 * k], rays_dir[3 * k + 1], rays_dir[3 * k + 2]);
+        return r;
+    }
+    if (g.sampler != RT_SAMPLER_FASTBLUE || S.cam.type == RT_CAM_APERTURE) {
+        double pos[2], v[2], aux[6];
+        sample_at(S, g, first + k, pos, v, aux);
+        return camera_emit(S.cam, v[0], v[1], aux[0], aux[1]);
+    }
+    const int64_t s = first + k;
+    const uint32_t tile = (uint32_t)(s / RT_BLUE_N);
+    const int i = (int)(s - (int64_t)tile * RT_BLUE_N);
+    const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+    const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
+    const double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + (double)tx * (double)RT_BLUE_NSQRT;
+    const double vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + (double)ty * (double)RT_BLUE_NSQRT;
+    const double v0 = (vx + g.adjust_x) * g.inv_size, v1 = (vy + g.adjust_y) * g.inv_size;
+    const RtCamera &c = S.cam;
+    const double kf = 35.0 * cull_rcp(c.focal);
+    const double x = (v0 - 0.5) * kf, y = (v1 - 0.5) * kf;
+    r.org = d3(c.org[0], c.org[1], c.org[2]);
+    if (c.type == RT_CAM_PERSPECTIVE) { r.dir = d3(x, y, -1.0); return r; }
+    if (c.type == RT_CAM_ORTHOGRAPHIC) { r.org = d3(x, y, c.org[2]); r.dir = d3(0.0, 0.0, -1.0); return r; }
+    const double id = cull_rcp(x * x + y * y + 4.0);
+    r.dir = d3(4.0 * x * id, 4.0 * y * id, 1.0 - 8.0 * id);
+    return r;
+}
+
 RT_DEV void root_frame(const RtPipe &P, int f, int k, const DRay &r, const double *aux)
 {
     d3_store(P.f_ray, P.fcap, 0, f, r.org);
@@ -154,9 +190,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         int k = k0 + it * 256 + threadIdx.x;
         bool keep = false;
         if (k < n) {
-            double aux[6];
-            DRay r;
-            root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
+            const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
             keep = scene_may_hit(S, lds, r, RT_INFINITY);
             if (!keep) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }

@@ -46,6 +46,7 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     int     test_row0, test_rows;       /* TEST sampler: output rows traced by this call */
     int     pad_;
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
+    double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;
 
 typedef struct RtSplatTable {   /* contributors of each pixel of a (40+2)^2 tile neighbourhood, CSR */
