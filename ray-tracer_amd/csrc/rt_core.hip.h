@@ -193,9 +193,12 @@ struct __attribute__((aligned(16))) HitRec {
     uint32_t leaf_affine;   /* index + 1, 0 = none */
     uint16_t surf, mat;
     uint16_t prim;          /* primitive index, or 0x8000 | clip index for an AngularClip wedge */
-    uint8_t  ntex;
-    uint8_t  tex[RT_MAX_TEX];
+    uint8_t  ntex, pad_;
+    uint32_t texpack;       /* up to RT_MAX_TEX (4) texture call-out indices, one byte each, first queued in the low byte */
 };
+#define HIT_TEX(h, k) (((h).texpack >> (8 * (k))) & 0xFFu)
+RT_DEV void hit_add_tex(HitRec &h, int tex) { if (tex >= 0 && h.ntex < RT_MAX_TEX) { h.texpack |= (uint32_t)tex << (8 * h.ntex); h.ntex++; } }
+
 
 struct Arena {              /* private (scratch) memory: lane-interleaved, uniform indices coalesce */
     HitRec   h[RT_ARENA];
@@ -204,6 +207,7 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     int32_t  l_gap[RT_LIST_STACK];      /* union regions: LCA depth between this entry and the one below it */
     uint16_t l_idx[RT_LIST_STACK];      /* union regions: last region child merged into this entry */
     int      nlist;
+    int      t_start, t_count, t_tag;   /* register mirror of the top list entry (valid when nlist > 0): avoids store -> load round trips */
     int      top;           /* first free hit slot */
     int      overflow;
     int      bail;          /* LITE interpreter met a rare, register-hungry feature: redo this ray in the FULL kernel */
@@ -235,6 +239,17 @@ struct Work {
 RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; }
 
 __device__ void arena_compact(Arena &A);
+RT_DEV void list_push(Arena &A, int start, int count, int tag)
+{
+    A.l_start[A.nlist] = (uint16_t)start; A.l_count[A.nlist] = (uint16_t)count; A.l_tag[A.nlist] = tag;
+    A.t_start = start; A.t_count = count; A.t_tag = tag;
+    A.nlist++;
+}
+RT_DEV void list_reload_top(Arena &A)
+{
+    if (A.nlist > 0) { A.t_start = A.l_start[A.nlist - 1]; A.t_count = A.l_count[A.nlist - 1]; A.t_tag = A.l_tag[A.nlist - 1]; }
+}
+RT_DEV void list_retag_top(Arena &A, int tag) { A.l_tag[A.nlist - 1] = tag; A.t_tag = tag; }
 
 /* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
 __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
@@ -269,20 +284,32 @@ __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_aff
         h.mat = inside ? 1 : 0;
         h.surf = (h.t > 0.0) ? 1 : 0;
         h.prim = prim;
-        h.ntex = 0;
+        h.ntex = 0; h.pad_ = 0; h.texpack = 0;
         inside = !inside;
     }
-    A.l_start[A.nlist] = (uint16_t)A.top;
-    A.l_count[A.nlist] = (uint16_t)nout;
-    A.l_tag[A.nlist] = tag;
-    A.nlist++;
+    list_push(A, A.top, nout, tag);
     A.top += nout;
+}
+
+/* Material::Intersect / Surface::Intersect (Solids.cpp:1466-1519) of a chain's wrappers, innermost first, applied to
+   one hit while it is still in registers */
+RT_DEV void hit_apply_wraps(const RtDevScene &S, const RtChain &ch, HitRec &h)
+{
+    for (int w = 0; w < ch.n_wrap; w++) {
+        const int wi = ch.wrap[w];
+        if (wi >= 0) {
+            if (S.mats[h.mat].density > 0.0) { h.mat = (uint16_t)wi; hit_add_tex(h, S.mats[wi].tex); }
+        } else if (h.t != 0.0) {
+            h.surf = (uint16_t)(~wi); hit_add_tex(h, S.surfs[~wi].tex);
+        }
+    }
 }
 
 /* HitList for solvers that return at most two roots (quadrics, polyhedra, slabs): the same rules as hit_list
    above, written without variable array indices so that the roots and normals stay in registers.
-   The list is (optional synthetic t = 0 hit) + (roots >= 0), at most three entries. */
-__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
+   The list is (optional synthetic t = 0 hit) + (roots >= 0), at most three entries.  With a chain, its wrappers
+   are applied before the records are stored. */
+__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtDevScene *S = 0, const RtChain *ch = 0)
 {
     const int count = w.count;
     const double r0 = WR(w, 0), r1 = WR(w, 1);
@@ -306,28 +333,30 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
     if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     const int last_in = w.inside_inf ? 1 : 0;
+    HitRec h;
+    h.leaf_affine = (uint32_t)(leaf_affine + 1); h.prim = prim; h.pad_ = 0;
     {
-        HitRec &h = A.h[A.top];
-        h.t = t0; h.n = n0; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.t = t0; h.n = n0; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 1) & 1) ? !last_in : last_in);
-        h.surf = (t0 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+        h.surf = (t0 > 0.0) ? 1 : 0;
+        if (ch) hit_apply_wraps(*S, *ch, h);
+        A.h[A.top] = h;
     }
     if (L >= 2) {
-        HitRec &h = A.h[A.top + 1];
-        h.t = t1; h.n = n1; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.t = t1; h.n = n1; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 2) & 1) ? !last_in : last_in);
-        h.surf = (t1 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+        h.surf = (t1 > 0.0) ? 1 : 0;
+        if (ch) hit_apply_wraps(*S, *ch, h);
+        A.h[A.top + 1] = h;
     }
     if (L >= 3) {
-        HitRec &h = A.h[A.top + 2];
-        h.t = t2; h.n = n2; h.leaf_affine = (uint32_t)(leaf_affine + 1);
+        h.t = t2; h.n = n2; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)last_in;
-        h.surf = (t2 > 0.0) ? 1 : 0; h.prim = prim; h.ntex = 0;
+        h.surf = (t2 > 0.0) ? 1 : 0;
+        if (ch) hit_apply_wraps(*S, *ch, h);
+        A.h[A.top + 2] = h;
     }
-    A.l_start[A.nlist] = (uint16_t)A.top;
-    A.l_count[A.nlist] = (uint16_t)L;
-    A.l_tag[A.nlist] = tag;
-    A.nlist++;
+    list_push(A, A.top, L, tag);
     A.top += L;
 }
 
@@ -437,7 +466,7 @@ RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
 }
 
 /* ================================================================== primitives */
-__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag)     /* Solids.cpp:325-358 */
+__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)     /* Solids.cpp:325-358 */
 {
     Work w;
     work_init(w);
@@ -455,10 +484,10 @@ __device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Ar
     }
     if (q.i0 == -1) { a = -a; b = -b; c = -c; }
     w.inside_inf = (a < 0.0) ? 1 : 0;
-    hit_list2(w, A, tag, prim, q.leaf_affine);
+    hit_list2(w, A, tag, prim, q.leaf_affine, S, ch);
 }
 
-__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag)   /* Solids.cpp:769-781 */
+__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)   /* Solids.cpp:769-781 */
 {
     Work w;
     work_init(w);
@@ -466,16 +495,16 @@ __device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, 
     int n = clip_plane(ray, d3(pl[0], pl[1], pl[2]), w, 0, 1.0);
     for (int i = 1; n && i < p.i0; i++)
         n = clip_plane(ray, d3(pl[3 * i], pl[3 * i + 1], pl[3 * i + 2]), w, 1, 1.0);
-    hit_list2(w, A, tag, prim, p.leaf_affine);
+    hit_list2(w, A, tag, prim, p.leaf_affine, S, ch);
 }
 
-__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag)        /* Solids.cpp:859-869 */
+__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)        /* Solids.cpp:859-869 */
 {
     Work w;
     work_init(w);
     int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
     if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
-    hit_list2(w, A, tag, prim, p.leaf_affine);
+    hit_list2(w, A, tag, prim, p.leaf_affine, S, ch);
 }
 
 RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
@@ -546,6 +575,7 @@ __device__ void arena_compact(Arena &A)
         const int s0 = A.l_start[l], c = A.l_count[l];
         if (s0 != top) for (int i = 0; i < c; i++) A.h[top + i] = A.h[s0 + i];
         A.l_start[l] = (uint16_t)top;
+        if (l == A.nlist - 1) A.t_start = top;
         top += c;
     }
     A.top = top;
@@ -554,12 +584,12 @@ __device__ void arena_compact(Arena &A)
 /* merge the two top lists (left below right) into one that takes the left list's place on the list stack */
 __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
 {
-    int li = A.nlist - 2, ri = A.nlist - 1;
-    int lc = A.l_count[li], rc = A.l_count[ri];
+    int li = A.nlist - 2;
+    int lc = A.l_count[li], rc = A.t_count;
     if (A.top + lc + rc > RT_ARENA) arena_compact(A);
-    int ls = A.l_start[li], rs = A.l_start[ri];
+    int ls = A.l_start[li], rs = A.t_start;
     int out = A.top, nout = 0;
-    if (out + lc + rc > RT_ARENA) { A.overflow = 1; A.nlist -= 1; A.l_tag[li] = tag; A.top = rs; return; }
+    if (out + lc + rc > RT_ARENA) { A.overflow = 1; A.nlist -= 1; A.top = rs; list_reload_top(A); list_retag_top(A, tag); return; }
     int il = 0, ir = 0;
     uint16_t ml = 0, mr = 0;
     double prev = mats[0].density;
@@ -581,26 +611,27 @@ __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
         }
     }
     if (nout == 1 && A.h[out].t == 0.0 && mats[A.h[out].mat].density == 0.0) nout = 0;     /* Solids.cpp:1053-1056 */
+    const int ridx = A.l_idx[A.nlist - 1];
     A.nlist -= 2;
     A.top = ls;
     if (nout > 0) {
         /* the merged entry keeps the left operand's l_gap and takes the right operand's l_idx */
-        A.l_start[A.nlist] = (uint16_t)out; A.l_count[A.nlist] = (uint16_t)nout; A.l_tag[A.nlist] = tag;
-        A.l_idx[A.nlist] = A.l_idx[A.nlist + 1];
-        A.nlist++;
+        A.l_idx[A.nlist] = (uint16_t)ridx;
+        list_push(A, out, nout, tag);
         A.top = out + nout;
-    }
+    } else
+        list_reload_top(A);
 }
 
-RT_DEV bool top_is(const Arena &A, int tag) { return A.nlist > 0 && A.l_tag[A.nlist - 1] == tag; }
+RT_DEV bool top_is(const Arena &A, int tag) { return A.nlist > 0 && A.t_tag == tag; }
 RT_DEV bool second_is(const Arena &A, int tag) { return A.nlist > 1 && A.l_tag[A.nlist - 2] == tag; }
-RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.l_start[A.nlist]; }
+RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.t_start; list_reload_top(A); }
 
 /* ================================================================== the per-ray stack machine
  * Evaluates psModel->Intersect(ray) (RayTracer2020.h:72): returns the hit list as [start, start+count)
  * in the arena.  tmax bounds the culling tests only (shadow rays stop at t = 1, Shade.cpp:328). */
 /* the innermost union region being folded lives in registers; enclosing ones are saved in private memory */
-struct RegionCur { int ncand, pos, base_lists, nl_before, out_tag, child_pc0, lca0, nchild, uid, end_pc, cur_c; };
+struct RegionCur { int ncand, pos, base_lists, nl_before, out_tag, child_pc0, lca0, nchild, uid, end_pc, cur_c, top_idx, top_gap; };
 
 /* min of lca[a .. b-1], a < b (RtRegion sparse table) */
 RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
@@ -728,7 +759,7 @@ template <bool LITE>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
-    RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, saved[RT_MAX_REGION_DEPTH];
+    RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 }, saved[RT_MAX_REGION_DEPTH];
     uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
     int nrf = 0;
     int depth = 0;
@@ -737,7 +768,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     long long t_cr = clock64();
 #endif
     const CullRay cr = cull_ray(wray, tmax);
-    A.nlist = 0; A.top = 0; A.overflow = 0; A.bail = 0;
+    A.nlist = 0; A.top = 0; A.overflow = 0; A.bail = 0; A.t_start = 0; A.t_count = 0; A.t_tag = -1;
 #ifdef RT_PHASE_PROF
     for (int q = 0; q < 12; q++) A.prof[q] = 0;
 #endif
@@ -780,36 +811,36 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
-            int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
+            int s = A.t_start, c = A.t_count;
             const RtMaterialDev &m = S.mats[in.a];
             for (int i = 0; i < c; i++) {
                 HitRec &h = A.h[s + i];
                 if (S.mats[h.mat].density > 0.0) {
                     h.mat = (uint16_t)in.a;
-                    if (m.tex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)m.tex;
+                    hit_add_tex(h, m.tex);
                 }
             }
-            A.l_tag[li] = in.tag;
+            list_retag_top(A, in.tag);
             break;
         }
         case OP_SURFACE: {                                      /* Surface::Intersect, Solids.cpp:1498-1519 */
             if (!top_is(A, 2 * in.b)) break;
-            int li = A.nlist - 1, s = A.l_start[li], c = A.l_count[li];
+            int s = A.t_start, c = A.t_count;
             const RtSurfaceDev &sf = S.surfs[in.a];
             for (int i = 0; i < c; i++) {
                 HitRec &h = A.h[s + i];
                 if (h.t == 0.0) continue;
                 h.surf = (uint16_t)in.a;
-                if (sf.tex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)sf.tex;
+                hit_add_tex(h, sf.tex);
             }
-            A.l_tag[li] = in.tag;
+            list_retag_top(A, in.tag);
             break;
         }
         case OP_UNION: {                                        /* Union::Intersect, Solids.cpp:1060-1075 */
             bool r = top_is(A, 2 * in.b + 1);
             bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
             if (l && r) merge_top(A, MERGE_MAX, S.mats, in.tag);
-            else if (l || r) A.l_tag[A.nlist - 1] = in.tag;
+            else if (l || r) list_retag_top(A, in.tag);
             break;
         }
         case OP_INTER: {                                        /* Intersection::Intersect, Solids.cpp:1139-1158 */
@@ -823,7 +854,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             bool r = top_is(A, 2 * in.b + 1);
             bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
             if (l && r) merge_top(A, MERGE_DIFF, S.mats, in.tag);
-            else if (l) A.l_tag[A.nlist - 1] = in.tag;
+            else if (l) list_retag_top(A, in.tag);
             else if (r) drop_top(A);
             break;
         }
@@ -843,7 +874,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             if (nrf > 0) saved[nrf - 1] = cf;
             cf.ncand = nc; cf.pos = 0; cf.base_lists = A.nlist; cf.nl_before = A.nlist; cf.out_tag = in.tag;
             cf.child_pc0 = rg.child_pc0; cf.lca0 = rg.lca0; cf.nchild = rg.n_children; cf.uid = rg.uid; cf.end_pc = rg.end_pc;
-            cf.cur_c = cd[0];
+            cf.cur_c = cd[0]; cf.top_idx = 0; cf.top_gap = -1;
             nrf++;
             pc = S.region_child_pc[cf.child_pc0 + cf.cur_c];
             break;
@@ -865,41 +896,20 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             {
                 PROF_BEGIN(tp);
                 switch (ch.prim_op) {
-                case OP_QUADRIC: quadric_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
-                case OP_POLY:    poly_hits(S.prims[ch.prim], (uint16_t)ch.prim, S.planes, r, A, in.tag); break;
-                case OP_SLAB:    slab_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break;
+                case OP_QUADRIC: quadric_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag, &S, &ch); break;
+                case OP_POLY:    poly_hits(S.prims[ch.prim], (uint16_t)ch.prim, S.planes, r, A, in.tag, &S, &ch); break;
+                case OP_SLAB:    slab_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag, &S, &ch); break;
                 default:
                     if constexpr (LITE) { A.bail = 1; goto done; }
-                    else { torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag); break; }
+                    else {
+                        torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag);
+                        if (A.nlist > before)
+                            for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(S, ch, h); A.h[A.t_start + i] = h; }
+                        break;
+                    }
                 }
                 PROF_END(A, 2, tp);
             }
-            PROF_BEGIN(tw);
-            if (A.nlist > before) {
-                const int li = A.nlist - 1, s0 = A.l_start[li], c = A.l_count[li];
-                for (int w = 0; w < ch.n_wrap; w++) {
-                    const int wi = ch.wrap[w];
-                    if (wi >= 0) {                                  /* Material::Intersect, Solids.cpp:1466-1487 */
-                        const int mtex = S.mats[wi].tex;
-                        for (int i = 0; i < c; i++) {
-                            HitRec &h = A.h[s0 + i];
-                            if (S.mats[h.mat].density > 0.0) {
-                                h.mat = (uint16_t)wi;
-                                if (mtex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)mtex;
-                            }
-                        }
-                    } else {                                        /* Surface::Intersect, Solids.cpp:1498-1519 */
-                        const int si = ~wi, stex = S.surfs[si].tex;
-                        for (int i = 0; i < c; i++) {
-                            HitRec &h = A.h[s0 + i];
-                            if (h.t == 0.0) continue;
-                            h.surf = (uint16_t)si;
-                            if (stex >= 0 && h.ntex < RT_MAX_TEX) h.tex[h.ntex++] = (uint8_t)stex;
-                        }
-                    }
-                }
-            }
-            PROF_END(A, 5, tw);
             if (in.b) goto region_ret;
             break;
         }
@@ -910,21 +920,25 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             const int ctag = 2 * cf.uid;
             const int c = cf.cur_c;
             if (A.nlist > cf.nl_before) {           /* the child left a list on top */
-                int e = A.nlist - 1;
+                const int e = A.nlist - 1;
+                const int gap = (e > cf.base_lists) ? region_gap(S, cf, cf.top_idx, c) : -1;
                 A.l_idx[e] = (uint16_t)c;
-                A.l_gap[e] = (e > cf.base_lists) ? region_gap(S, cf, A.l_idx[e - 1], c) : -1;
+                A.l_gap[e] = gap;
+                cf.top_idx = c; cf.top_gap = gap;
             }
             cf.pos++;
             if (cf.pos < cf.ncand) {
                 const int next = cands[nrf - 1][cf.pos];
-                while (A.nlist - cf.base_lists >= 2 && A.l_gap[A.nlist - 1] > region_gap(S, cf, A.l_idx[A.nlist - 1], next))
+                while (A.nlist - cf.base_lists >= 2 && cf.top_gap > region_gap(S, cf, cf.top_idx, next)) {
                     merge_top(A, MERGE_MAX, S.mats, ctag);
+                    if (A.nlist > cf.base_lists) { cf.top_gap = A.l_gap[A.nlist - 1]; cf.top_idx = A.l_idx[A.nlist - 1]; }
+                }
                 cf.nl_before = A.nlist;
                 cf.cur_c = next;
                 pc = S.region_child_pc[cf.child_pc0 + next];
             } else {
                 while (A.nlist - cf.base_lists >= 2) merge_top(A, MERGE_MAX, S.mats, ctag);
-                if (A.nlist - cf.base_lists == 1) A.l_tag[A.nlist - 1] = cf.out_tag;
+                if (A.nlist - cf.base_lists == 1) list_retag_top(A, cf.out_tag);
                 nrf--;
                 pc = cf.end_pc;
                 if (nrf > 0) cf = saved[nrf - 1];
@@ -945,7 +959,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             else {
                 /* Merge(body, empty): every body hit is still filtered through op(pmLeft, vacuum) */
                 if (A.top + 1 <= RT_ARENA && A.nlist < RT_LIST_STACK) {
-                    A.l_start[A.nlist] = (uint16_t)A.top; A.l_count[A.nlist] = 0; A.l_tag[A.nlist] = 2 * in.b + 1; A.nlist++;
+                    list_push(A, A.top, 0, 2 * in.b + 1);
                     merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
                 } else A.overflow = 1;
             }
@@ -958,7 +972,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
 done:
     PROF_END(A, 3, t_all);
     if (A.bail) { start = 0; return 0; }
-    if (A.nlist > 0 && A.l_tag[A.nlist - 1] == 0) { start = A.l_start[A.nlist - 1]; return A.l_count[A.nlist - 1]; }
+    if (A.nlist > 0 && A.t_tag == 0) { start = A.t_start; return A.t_count; }
     start = 0;
     return 0;
 }
@@ -1157,8 +1171,8 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
     int it = 0, nt = hr.ntex;
     int pa;
     for (pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) {
-        while (it < nt && S.texnodes[hr.tex[it]].pa == pa) {
-            const RtTexNode &tn = S.texnodes[hr.tex[it]];
+        while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == pa) {
+            const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
             DRay lr = ray_in_frame(S, wray, tn.tree_affine);
             apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
             it++;
@@ -1166,8 +1180,8 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
         h.n = covec_mat(h.n, S.affines[pa].minv);
         if (h.perturbed) h.np = covec_mat(h.np, S.affines[pa].minv);
     }
-    while (it < nt && S.texnodes[hr.tex[it]].pa == -1) {
-        const RtTexNode &tn = S.texnodes[hr.tex[it]];
+    while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == -1) {
+        const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
         DRay lr = ray_in_frame(S, wray, tn.tree_affine);
         apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
         it++;
