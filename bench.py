@@ -68,7 +68,14 @@ def main():
     gs = rt.GpuScene(fs.desc)
     # contiguous row bands; every rank traces its own halo, so the data path has no exchange
     sh = rt.sharding
-    rows = sh.row_bands(H, world)
+    if world > 1:
+        # cost-balanced bands from a tiny 1-spp preview that every rank renders for itself (deterministic, no exchange)
+        ps = rt.FrontScene(args.scene, "test", optimize=True)
+        ph, pw = max(16, H // 16), max(16, W // 16)
+        preview, _ = rt.GpuScene(ps.desc).render(pw, ph, 1)
+        rows = sh.balanced_bands(sh.row_cost_from_preview(preview, H), world)
+    else:
+        rows = sh.row_bands(H, world)
     row0, row1 = rows[rank], rows[rank + 1]
     planes = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -117,7 +124,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64)" % (args.scene, W, H, spp),
                        "scene": args.scene, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
-                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world},
+                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows},
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace)

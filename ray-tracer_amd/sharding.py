@@ -9,6 +9,38 @@ def row_bands(height, world):
     return [(height * r) // world for r in range(world + 1)]
 
 
+def balanced_bands(row_cost, world):
+    """Band boundaries with (nearly) equal summed cost: row_cost[j] > 0 is a relative cost estimate of output row j.
+    Deterministic in its inputs, so every rank derives the same bands without talking to the others."""
+    h = len(row_cost)
+    if world <= 1 or h == 0:
+        return [0, h]
+    total = float(sum(row_cost))
+    bands, acc, j = [0], 0.0, 0
+    for r in range(1, world):
+        target = total * r / world
+        while j < h and acc + row_cost[j] <= target:
+            acc += row_cost[j]
+            j += 1
+        j = max(j, bands[-1])
+        bands.append(min(j, h))
+    bands.append(h)
+    return bands
+
+
+def row_cost_from_preview(preview, height, hit_weight=6.6):
+    """Relative cost of each of `height` output rows from a small preview image [3][h][w] of the same view: every row
+    pays for sample generation and reconstruction (1.0), rows whose pixels see geometry also pay for intersection and
+    shading (hit_weight x the fraction of non-black pixels; 6.6 is the measured ratio on the MI355X kernels)."""
+    import numpy as np
+    hit = (np.abs(np.asarray(preview)).sum(axis=0) > 0).mean(axis=1)          # fraction of hit pixels per preview row
+    hp = len(hit)
+    # a row also pays for its neighbours' samples (filter halo): smooth over +-1 preview row
+    sm = np.convolve(np.pad(hit, 1, mode="edge"), np.ones(3) / 3.0, mode="valid")
+    idx = np.minimum((np.arange(height) * hp) // max(height, 1), hp - 1)
+    return (1.0 + hit_weight * sm[idx]).tolist()
+
+
 def plan_rows(rt_lib, desc_cls, sampler, width, height, spp, row0, row1):
     """rt_plan_rows (include/rt_amd.h): supersample rows and tile rows a band needs.  Host only."""
     out = (C.c_int * 8)()

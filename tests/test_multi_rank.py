@@ -85,3 +85,23 @@ def test_halo_covers_every_contributing_sample(rt, oracle, width, height, spp, w
         touches = (lo_row + 1 >= p["src_y0"]) & (lo_row <= p["src_y1"] - 1)
         inside = (tile_y >= p["tile_y0"]) & (tile_y < p["tile_y0"] + p["tiles_y"])
         assert not np.any(touches & ~inside), "band %d misses contributing samples" % r
+
+
+def test_balanced_bands_equalise_cost():
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    rng = np.random.default_rng(5)
+    for h, w in ((2160, 8), (100, 3), (17, 4), (5, 8)):
+        cost = (1.0 + 6.0 * (rng.random(h) < 0.3) * rng.random(h)).tolist()
+        b = rt.sharding.balanced_bands(cost, w)
+        assert len(b) == w + 1 and b[0] == 0 and b[-1] == h and all(b[i] <= b[i + 1] for i in range(w))
+        if h >= 20 * w:
+            sums = [sum(cost[b[i]:b[i + 1]]) for i in range(w)]
+            assert max(sums) <= 1.15 * (sum(cost) / w) + max(cost)
+    assert rt.sharding.balanced_bands([1.0] * 10, 1) == [0, 10]
+    # a preview with geometry only in the middle pulls the band boundaries towards the middle
+    prev = np.zeros((3, 32, 32), dtype=np.float32)
+    prev[:, 12:20, :] = 1.0
+    cost = rt.sharding.row_cost_from_preview(prev, 320)
+    b = rt.sharding.balanced_bands(cost, 4)
+    assert b[1] > 80 and b[3] < 240 and (b[2] - b[1]) < 80

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One-GPU rehearsal of the multi-GPU split: render every rank's band of one frame in turn and report the per-band
+times for equal-height and cost-balanced bands (the frame time on N GPUs is the slowest band)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+
+rt = ge.load_package()
+W, H, spp, scene = 3840, 2160, 64, (sys.argv[1] if len(sys.argv) > 1 else "S0")
+fs = rt.FrontScene(scene, "fastblue", optimize=True)       # keep the front-end scene alive: the description points into it
+gs = rt.GpuScene(fs.desc)
+planes = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+gs.render_device(W, H, spp, planes.data_ptr(), 0)          # warm-up, allocations
+torch.cuda.synchronize()
+t0 = time.perf_counter(); gs.render_device(W, H, spp, planes.data_ptr(), 0); torch.cuda.synchronize()
+full = time.perf_counter() - t0
+ps = rt.FrontScene(scene, "test", optimize=True)
+prev, _ = rt.GpuScene(ps.desc).render(W // 16, H // 16, 1)
+cost = rt.sharding.row_cost_from_preview(prev, H)
+for world in (2, 4, 8):
+    for name, bands in (("equal", rt.sharding.row_bands(H, world)), ("balanced", rt.sharding.balanced_bands(cost, world))):
+        ts = []
+        for r in range(world):
+            if bands[r] == bands[r + 1]:
+                ts.append(0.0); continue
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            gs.render_device(W, H, spp, planes.data_ptr(), 0, bands[r], bands[r + 1])
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print("%s world %d %-8s full %.1f ms  slowest band %.1f ms  -> efficiency %.2f   bands %s" %
+              (scene, world, name, 1e3 * full, 1e3 * max(ts), full / (world * max(ts)), bands))
