@@ -293,14 +293,15 @@ __device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_aff
 
 /* Material::Intersect / Surface::Intersect (Solids.cpp:1466-1519) of a chain's wrappers, innermost first, applied to
    one hit while it is still in registers */
-RT_DEV void hit_apply_wraps(const RtDevScene &S, const RtChain &ch, HitRec &h)
+RT_DEV void hit_apply_wraps(const RtChain &ch, HitRec &h)
 {
+    bool dense = h.mat != 0;            /* a fresh hit enters vacuum (0, density 0) or neutronium (1, density 1e6) */
     for (int w = 0; w < ch.n_wrap; w++) {
         const int wi = ch.wrap[w];
         if (wi >= 0) {
-            if (S.mats[h.mat].density > 0.0) { h.mat = (uint16_t)wi; hit_add_tex(h, S.mats[wi].tex); }
+            if (dense) { h.mat = (uint16_t)wi; hit_add_tex(h, ch.wrap_tex[w]); dense = (ch.wrap_dense >> w) & 1; }
         } else if (h.t != 0.0) {
-            h.surf = (uint16_t)(~wi); hit_add_tex(h, S.surfs[~wi].tex);
+            h.surf = (uint16_t)(~wi); hit_add_tex(h, ch.wrap_tex[w]);
         }
     }
 }
@@ -309,7 +310,7 @@ RT_DEV void hit_apply_wraps(const RtDevScene &S, const RtChain &ch, HitRec &h)
    above, written without variable array indices so that the roots and normals stay in registers.
    The list is (optional synthetic t = 0 hit) + (roots >= 0), at most three entries.  With a chain, its wrappers
    are applied before the records are stored. */
-__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtDevScene *S = 0, const RtChain *ch = 0)
+__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtChain *ch = 0)
 {
     const int count = w.count;
     const double r0 = WR(w, 0), r1 = WR(w, 1);
@@ -339,21 +340,21 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
         h.t = t0; h.n = n0; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 1) & 1) ? !last_in : last_in);
         h.surf = (t0 > 0.0) ? 1 : 0;
-        if (ch) hit_apply_wraps(*S, *ch, h);
+        if (ch) hit_apply_wraps(*ch, h);
         A.h[A.top] = h;
     }
     if (L >= 2) {
         h.t = t1; h.n = n1; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 2) & 1) ? !last_in : last_in);
         h.surf = (t1 > 0.0) ? 1 : 0;
-        if (ch) hit_apply_wraps(*S, *ch, h);
+        if (ch) hit_apply_wraps(*ch, h);
         A.h[A.top + 1] = h;
     }
     if (L >= 3) {
         h.t = t2; h.n = n2; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)last_in;
         h.surf = (t2 > 0.0) ? 1 : 0;
-        if (ch) hit_apply_wraps(*S, *ch, h);
+        if (ch) hit_apply_wraps(*ch, h);
         A.h[A.top + 2] = h;
     }
     list_push(A, A.top, L, tag);
@@ -466,7 +467,7 @@ RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
 }
 
 /* ================================================================== primitives */
-__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)     /* Solids.cpp:325-358 */
+__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)     /* Solids.cpp:325-358 */
 {
     Work w;
     work_init(w);
@@ -484,10 +485,10 @@ __device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Ar
     }
     if (q.i0 == -1) { a = -a; b = -b; c = -c; }
     w.inside_inf = (a < 0.0) ? 1 : 0;
-    hit_list2(w, A, tag, prim, q.leaf_affine, S, ch);
+    hit_list2(w, A, tag, prim, q.leaf_affine, ch);
 }
 
-__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)   /* Solids.cpp:769-781 */
+__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)   /* Solids.cpp:769-781 */
 {
     Work w;
     work_init(w);
@@ -495,16 +496,16 @@ __device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, 
     int n = clip_plane(ray, d3(pl[0], pl[1], pl[2]), w, 0, 1.0);
     for (int i = 1; n && i < p.i0; i++)
         n = clip_plane(ray, d3(pl[3 * i], pl[3 * i + 1], pl[3 * i + 2]), w, 1, 1.0);
-    hit_list2(w, A, tag, prim, p.leaf_affine, S, ch);
+    hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
 
-__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtDevScene *S = 0, const RtChain *ch = 0)        /* Solids.cpp:859-869 */
+__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)        /* Solids.cpp:859-869 */
 {
     Work w;
     work_init(w);
     int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
     if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
-    hit_list2(w, A, tag, prim, p.leaf_affine, S, ch);
+    hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
 
 RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
@@ -642,21 +643,26 @@ RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
     return x < y ? x : y;
 }
 
-/* workgroup-shared staging in dynamic LDS (size RtDevScene.lds_bytes, blockDim.x == 256): the first n_bvh_lds
-   nodes of the scene's BVH, then the per-lane traversal stacks */
-struct SceneLds { const double *bvh; uint16_t *stack; int n_nodes; };
-#define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * 256 + (lane)]
+/* workgroup-shared staging in dynamic LDS: the first n_nodes nodes of the scene's BVH, the scene's chain records
+   (persistent kernels, when they all fit), then the per-lane traversal stacks (RT_BVH_STACK x blockDim.x x 2 B).
+   The host sizes the allocation (rt_scene_upload: lds_small / lds_visual / lds_shadow). */
+struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int n_nodes, n_chains, stride; };
+#define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * (L).stride + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
-RT_DEV SceneLds scene_lds_load(const RtDevScene &S)
+RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds)
 {
     extern __shared__ double rt_dyn_lds[];
     SceneLds L;
     L.n_nodes = S.n_bvh_lds;
-    int words = L.n_nodes * (int)(sizeof(RtBvhNode) / 8);
-    const double *src = (const double *)S.bvh;
-    for (int k = threadIdx.x; k < words; k += blockDim.x) rt_dyn_lds[k] = src[k];
+    L.n_chains = n_chains_lds;
+    L.stride = blockDim.x;
+    const int words_bvh = L.n_nodes * (int)(sizeof(RtBvhNode) / 8), words_ch = L.n_chains * (int)(sizeof(RtChain) / 8);
+    const double *src = (const double *)S.bvh, *src2 = (const double *)S.chains;
+    for (int k = threadIdx.x; k < words_bvh; k += blockDim.x) rt_dyn_lds[k] = src[k];
+    for (int k = threadIdx.x; k < words_ch; k += blockDim.x) rt_dyn_lds[words_bvh + k] = src2[k];
     L.bvh = rt_dyn_lds;
-    L.stack = (uint16_t *)(rt_dyn_lds + words);
+    L.chains = (const RtChain *)(rt_dyn_lds + words_bvh);
+    L.stack = (uint16_t *)(rt_dyn_lds + words_bvh + words_ch);
     __syncthreads();
     return L;
 }
@@ -755,7 +761,7 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
 /* LITE = true compiles the rare, register-hungry features out (torus quartics here; texture call-outs, propagators
    and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
    The split keeps the common kernels small enough for several waves per SIMD. */
-template <bool LITE>
+template <bool LITE, bool CH_LDS = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
@@ -881,30 +887,34 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         }
         case OP_CHAIN: {
             PROF_BEGIN(tc);
-            const RtChain &ch = S.chains[in.a];
+            /* CH_LDS: every chain record of the scene is staged in LDS (decided per launch, so that the loads below
+               are LDS loads and not generic ones) */
+            const RtChain &ch = CH_LDS ? L.chains[in.a] : S.chains[in.a];
             if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b) goto region_ret; break; }
             DRay r = cur;
-            for (int k = 0; k < ch.n_affine; k++) {                 /* AffineSolid::Intersect, Solids.cpp:899-913 */
-                const RtAffine &a = S.affines[ch.affine[k]];
+            if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
                 DRay nr;
-                nr.dir = mat_vec(a.minv, r.dir);
-                nr.org = mat_vec(a.minv, r.org - d3(a.tr[0], a.tr[1], a.tr[2]));
+                nr.dir = mat_vec(ch.minv, r.dir);
+                nr.org = mat_vec(ch.minv, r.org - d3(ch.tr[0], ch.tr[1], ch.tr[2]));
                 r = nr;
             }
+            RtPrim pr;
+            pr.p[0] = ch.p[0]; pr.p[1] = ch.p[1]; pr.p[2] = ch.p[2]; pr.p[3] = 0.0;
+            pr.i0 = ch.i0; pr.plane0 = ch.plane0; pr.leaf_affine = ch.leaf_affine; pr.id = 0;
             const int before = A.nlist;
             PROF_END(A, 4, tc);
             {
                 PROF_BEGIN(tp);
                 switch (ch.prim_op) {
-                case OP_QUADRIC: quadric_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag, &S, &ch); break;
-                case OP_POLY:    poly_hits(S.prims[ch.prim], (uint16_t)ch.prim, S.planes, r, A, in.tag, &S, &ch); break;
-                case OP_SLAB:    slab_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag, &S, &ch); break;
+                case OP_QUADRIC: quadric_hits(pr, (uint16_t)ch.prim, r, A, in.tag, &ch); break;
+                case OP_POLY:    poly_hits(pr, (uint16_t)ch.prim, S.planes, r, A, in.tag, &ch); break;
+                case OP_SLAB:    slab_hits(pr, (uint16_t)ch.prim, r, A, in.tag, &ch); break;
                 default:
                     if constexpr (LITE) { A.bail = 1; goto done; }
                     else {
-                        torus_hits(S.prims[ch.prim], (uint16_t)ch.prim, r, A, in.tag);
+                        torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
-                            for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(S, ch, h); A.h[A.t_start + i] = h; }
+                            for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
                         break;
                     }
                 }

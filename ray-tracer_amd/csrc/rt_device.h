@@ -128,6 +128,7 @@ typedef struct RtRegion {
    are staged in LDS by every workgroup. */
 #define RT_BVH_EMPTY     ((int32_t)0x80000000)
 #define RT_LDS_BVH_NODES 192        /* 192 * 208 B = 39 KB of LDS */
+#define RT_LDS_CHAINS    320        /* 320 * 208 B = 65 KB of LDS (persistent tracing kernels only) */
 #define RT_BVH_STACK     28         /* pending nodes per ray (LDS, 2 B each) */
 typedef struct RtBvhNode {
     double  lo[3][4], hi[3][4];
@@ -135,16 +136,24 @@ typedef struct RtBvhNode {
 } RtBvhNode;
 
 /* A chain: single-child wrappers around one primitive, the commonest shape of a scene object
-   (Translate(Scale(Material(Surface(Sphere))))).  Evaluated by one OP_CHAIN instead of
-   [BOUND] PUSH_AFFINE.. primitive MATERIAL/SURFACE.. POP_AFFINE..: same operations in the same order. */
-#define RT_CHAIN_AFFINES 3
+   (Translate(Scale(Material(Surface(Sphere)))) -- after Optimize() one merged affine at most).  Evaluated by one
+   OP_CHAIN instead of [BOUND] PUSH_AFFINE primitive MATERIAL/SURFACE.. POP_AFFINE: same operations in the same
+   order.  The record is self-contained (208 bytes: the affine, the primitive's parameters, what the wrappers do to
+   a hit), so that one ray needs one record, and the first records of a scene are staged in LDS. */
 #define RT_CHAIN_WRAPS   6
 typedef struct RtChain {
-    int32_t prim_op, prim;
-    int32_t box;            /* the chain's conservative world box, -1 = unbounded */
-    int32_t test_box;       /* 0 when the caller (a region's BVH leaf) has already tested that box */
-    int32_t n_affine, affine[RT_CHAIN_AFFINES];     /* outermost first */
-    int32_t n_wrap, wrap[RT_CHAIN_WRAPS];           /* innermost first; >= 0: material index, < 0: ~surface index */
+    double  minv[9], tr[3];     /* the affine (n_affine == 1): AffineSolid after Optimize(), Solids.cpp:957-983 */
+    double  p[3];               /* quadric P,Q,R ; torus: minor radius in p[0] */
+    int32_t prim_op, prim;      /* OP_QUADRIC.. ; index into prims (ids for the probes) */
+    int32_t i0, plane0;         /* quadric nClip / polyhedron nSides ; first plane */
+    int32_t leaf_affine;        /* affine the hits record (s_paLastHitAffine, Solids.cpp:213), -1 none */
+    int32_t n_affine;           /* 0 or 1 */
+    int32_t box;                /* the chain's conservative world box, -1 = unbounded */
+    int32_t test_box;           /* 0 when the caller (a region's BVH leaf) has already tested that box */
+    int32_t n_wrap;
+    int32_t wrap_dense;         /* bit w: wrapper w is a material of density > 0 */
+    int32_t wrap[RT_CHAIN_WRAPS];       /* innermost first; >= 0: material index, < 0: ~surface index */
+    int32_t wrap_tex[RT_CHAIN_WRAPS];   /* texture call-out the wrapper queues, -1 none */
 } RtChain;
 
 typedef struct RtLightDev {
@@ -175,7 +184,7 @@ typedef struct RtDevScene {
     const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
     int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
-    int32_t n_bvh_lds, lds_bytes;       /* BVH nodes staged in LDS; dynamic LDS bytes of every kernel that traces */
+    int32_t n_bvh_lds, n_chains;        /* BVH nodes staged in LDS; number of chain records */
     int32_t root_cull, root_cull_arg;   /* 0: none; 1: the whole program is union region root_cull_arg; 2: ... is one chain with box root_cull_arg */
     float   ambient[RT_NSPEC];
     float   spec2rgb[RT_NSPEC][3];

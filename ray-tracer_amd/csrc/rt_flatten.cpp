@@ -416,7 +416,7 @@ struct Flattener {
         else if (lt == RT_NODE_SLAB) op = OP_SLAB;
         else if (lt == RT_NODE_TORUS) op = OP_TORUS;
         else return false;
-        if (na > RT_CHAIN_AFFINES || nw > RT_CHAIN_WRAPS) return false;
+        if (na > 1 || nw > RT_CHAIN_WRAPS) return false;
         if ((int)affine_stack.size() + na > RT_MAX_AFFINE_DEPTH) return false;      /* let the general code report it */
         RtChain ch;
         memset(&ch, 0, sizeof ch);
@@ -426,7 +426,9 @@ struct Flattener {
             if (b.empty && !no_root_bound) return true;         /* statically empty: nothing to emit */
             if (!b.empty && b.finite()) { ch.box = add_box(b, true); ch.test_box = no_root_bound ? 0 : 1; if (ch.test_box) o.culled_subtrees++; }
         }
-        int wraps[RT_CHAIN_WRAPS], tex_added = 0;
+        ch.leaf_affine = -1;
+        for (int k = 0; k < RT_CHAIN_WRAPS; k++) ch.wrap_tex[k] = -1;
+        int wraps[RT_CHAIN_WRAPS], wtex[RT_CHAIN_WRAPS], wdense[RT_CHAIN_WRAPS], tex_added = 0;
         for (size_t k = 0; k < path.size(); k++) {
             int j = path[k];
             const RtNode &n = N(j);
@@ -443,7 +445,8 @@ struct Flattener {
                 Fwd f; memcpy(f.m, p, sizeof f.m); memcpy(f.t, p + 18, sizeof f.t);
                 affine_stack.push_back(ai); fwd_stack.push_back(f);
                 last_affine = ai;
-                ch.affine[ch.n_affine++] = ai;
+                memcpy(ch.minv, a.minv, sizeof ch.minv); memcpy(ch.tr, a.tr, sizeof ch.tr);
+                ch.n_affine = 1;
             } else if (n.type == RT_NODE_MATERIAL) {
                 if (n.i0 < RT_MAT_NOSHADE || n.i0 > RT_MAT_TITANIUM) return fail(RT_ERR_INVALID, "material luster out of range"), true;
                 if (n.i2 < 0 || n.i2 >= RT_PROP__COUNT) return fail(RT_ERR_UNSUPPORTED, "unknown propagator"), true;
@@ -454,6 +457,7 @@ struct Flattener {
                 m.luster = n.i0; m.prop = n.i2; m.id = n.id;
                 if (n.i1) { tex_added++; if (++tex_depth > RT_MAX_TEX) return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"), true; }
                 m.tex = tex_node(n.i1, n.link);
+                wtex[ch.n_wrap] = m.tex; wdense[ch.n_wrap] = m.density > 0.0 ? 1 : 0;
                 wraps[ch.n_wrap++] = (int)o.mats.size();
                 o.mats.push_back(m);
             } else {
@@ -462,13 +466,23 @@ struct Flattener {
                 sf.roughness = n.i0; sf.id = n.id;
                 if (n.i1) { tex_added++; if (++tex_depth > RT_MAX_TEX) return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_TEX textured ancestors"), true; }
                 sf.tex = tex_node(n.i1, n.link);
+                wtex[ch.n_wrap] = sf.tex; wdense[ch.n_wrap] = 0;
                 wraps[ch.n_wrap++] = ~(int)o.surfs.size();
                 o.surfs.push_back(sf);
             }
         }
         ch.prim_op = op;
         ch.prim = leaf(op, c);
-        for (int k = 0; k < ch.n_wrap; k++) ch.wrap[k] = wraps[ch.n_wrap - 1 - k];     /* innermost first */
+        {
+            const RtPrim &pr = o.prims[ch.prim];
+            ch.p[0] = pr.p[0]; ch.p[1] = pr.p[1]; ch.p[2] = pr.p[2];
+            ch.i0 = pr.i0; ch.plane0 = pr.plane0; ch.leaf_affine = pr.leaf_affine;
+        }
+        for (int k = 0; k < ch.n_wrap; k++) {                   /* innermost first */
+            int src = ch.n_wrap - 1 - k;
+            ch.wrap[k] = wraps[src]; ch.wrap_tex[k] = wtex[src];
+            if (wdense[src]) ch.wrap_dense |= 1 << k;
+        }
         for (int k = 0; k < ch.n_affine; k++) { affine_stack.pop_back(); fwd_stack.pop_back(); }
         tex_depth -= tex_added;
         o.chains.push_back(ch);

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 {
     const RtDevScene &S = Sv;
     __shared__ int wave_count[RT_GEN_ITERS][4], wave_base[RT_GEN_ITERS][4], block_base;
-    const SceneLds lds = scene_lds_load(S);
+    const SceneLds lds = scene_lds_load(S, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = blockIdx.x * RT_GEN_SPAN;
     unsigned keep_bits = 0;
@@ -220,33 +220,37 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
     }
 }
 
-#ifndef RT_LITE_VISUAL_WAVES
-#define RT_LITE_VISUAL_WAVES 3   /* minimum waves per SIMD the common kernels are compiled for */
+/* workgroup sizes of the common (LITE) kernels: one workgroup per CU, 3 resp. 4 waves per SIMD, which also bounds
+   their VGPRs (512 / waves per SIMD) */
+#ifndef RT_LITE_VISUAL_THREADS
+#define RT_LITE_VISUAL_THREADS 768
 #endif
-#ifndef RT_LITE_SHADOW_WAVES
-#define RT_LITE_SHADOW_WAVES 4
+#ifndef RT_LITE_SHADOW_THREADS
+#define RT_LITE_SHADOW_THREADS 1024
 #endif
 /* ------------------------------------------------------------------ k_visual
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
  * LITE = true is the common kernel: a ray that meets a torus, a textured hit, a propagating medium or a spectral
  * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
-template <bool LITE>
-__global__ void __launch_bounds__(256, LITE ? RT_LITE_VISUAL_WAVES : 1) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1)
+template <bool LITE, bool CH_LDS>
+__global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     const RtDevScene &S = Sv;
+    const SceneLds lds = scene_lds_load(S, n_chains_lds);
+    /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
+       in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
+    const int n = LITE ? (f1 - f0) : P.counters[CTR_SLOW_V];
+    int *const work = &P.counters[LITE ? CTR_WORK_V : CTR_WORK_VS];
+    const int wlane = threadIdx.x & 63;
+  for (;;) {
+    int wbase = 0;
+    if (wlane == 0) wbase = atomicAdd(work, 64);
+    wbase = __shfl(wbase, 0, 64);
+    if (wbase >= n) break;
+    const bool live = wbase + wlane < n;
     int f;
-    bool live;
-    if constexpr (LITE) {
-        f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
-        live = f < f1;
-    } else {
-        const int n = P.counters[CTR_SLOW_V];
-        if ((int)(blockIdx.x * blockDim.x) >= n) return;
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        live = i < n;
-        f = live ? P.slow_v[i] : 0;
-    }
-    const SceneLds lds = scene_lds_load(S);
+    if constexpr (LITE) f = f0 + wbase + wlane;
+    else f = live ? P.slow_v[wbase + wlane] : 0;
 #ifdef RT_PHASE_PROF
     long long prof_t0 = clock64();
     int prof_v[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(256, LITE ? RT_LITE_VISUAL_WAVES : 1) k_visual
         for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
         Arena A;
         int start;
-        int count = intersect_scene<LITE>(S, lds, ray, RT_INFINITY, A, start);
+        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start);
         if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
@@ -378,7 +382,7 @@ __global__ void __launch_bounds__(256, LITE ? RT_LITE_VISUAL_WAVES : 1) k_visual
         if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 4);
     }
 #endif
-    if (!live || bail) return;
+    if (!live || bail) continue;
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
     P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
     P.f_flags[f] = flags;
@@ -397,27 +401,28 @@ __global__ void __launch_bounds__(256, LITE ? RT_LITE_VISUAL_WAVES : 1) k_visual
             P.s_root[s] = P.f_root[f];
         }
     }
+  }
 }
 
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
-template <bool LITE>
-__global__ void __launch_bounds__(256, LITE ? RT_LITE_SHADOW_WAVES : 1) k_shadow(const RtDevScene Sv, RtPipe P, int n)
+template <bool LITE, bool CH_LDS>
+__global__ void __launch_bounds__(LITE ? RT_LITE_SHADOW_THREADS : 256) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     const RtDevScene &S = Sv;
+    const SceneLds lds = scene_lds_load(S, n_chains_lds);
+    const int n = LITE ? nrays : P.counters[CTR_SLOW_S];
+    int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
+    const int wlane = threadIdx.x & 63;
+  for (;;) {
+    int wbase = 0;
+    if (wlane == 0) wbase = atomicAdd(work, 64);
+    wbase = __shfl(wbase, 0, 64);
+    if (wbase >= n) break;
+    const bool live = wbase + wlane < n;
     int s;
-    bool live;
-    if constexpr (LITE) {
-        s = blockIdx.x * blockDim.x + threadIdx.x;
-        live = s < n;
-    } else {
-        const int m = P.counters[CTR_SLOW_S];
-        if ((int)(blockIdx.x * blockDim.x) >= m) return;
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        live = i < m;
-        s = live ? P.slow_s[i] : 0;
-    }
-    const SceneLds lds = scene_lds_load(S);
+    if constexpr (LITE) s = wbase + wlane;
+    else s = live ? P.slow_s[wbase + wlane] : 0;
     bool bail = false;
     if (live) {
         DRay ray;
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(256, LITE ? RT_LITE_SHADOW_WAVES : 1) k_shadow
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
         Arena A;
         int start;
-        int count = intersect_scene<LITE>(S, lds, ray, 1.0, A, start);
+        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, 1.0, A, start);
         if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
         bail = A.bail != 0;
         int i = 0, pm = 0;
@@ -485,6 +490,7 @@ __global__ void __launch_bounds__(256, LITE ? RT_LITE_SHADOW_WAVES : 1) k_shadow
         int slot = wave_alloc(bail ? 1 : 0, &P.counters[CTR_SLOW_S]);
         if (bail) P.slow_s[slot] = s;
     }
+  }
 }
 
 /* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
@@ -607,7 +613,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
-    const SceneLds lds = scene_lds_load(S);
+    const SceneLds lds = scene_lds_load(S, 0);
     if (k >= n) return;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
@@ -649,7 +655,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const RtDevScene &S = Sv;
-    const SceneLds lds = scene_lds_load(S);
+    const SceneLds lds = scene_lds_load(S, 0);
     if (k >= n) return;
     DRay ray;
     ray.org = d3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
