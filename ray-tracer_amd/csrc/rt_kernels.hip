@@ -493,14 +493,17 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_SHADOW_THREADS : 256) k_shadow(
   }
 }
 
+RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec);
+
 /* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
-__global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1)
+__global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
 {
     int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = f < f1;
     const RtDevScene &S = Sv;
     int nchild = 0, flags = 0;
-    bool want_refl = false, want_refr = false;
+    bool want_refl = false, want_refr = false, have_R = false;
+    Spec Rfin;
     D3 Ppt = d3(0, 0, 0), dir_refl = d3(0, 0, 0), dir_refr = d3(0, 0, 0);
     int depth = 0;
     if (live) {
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
                 Spec refl = brdf(rough, luster, color, hn, vL, vE, cvN, F);
                 R = R + refl * E;
             }
-            spec_store(P.f_R, P.fcap, f, R);
+            Rfin = R; have_R = true;
             if (rough == RT_SURF_POLISHED) {
                 int perturbed = (flags & FR_PERTURBED) ? 1 : 0;
                 if (F != 0.0 && depth + 1 < 6) {
@@ -551,6 +554,18 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
                     else spec_store(P.f_c2, P.fcap, f, spec_const(0.0f));
                 }
             }
+        }
+        /* A frame without reflection / refraction terms is finished here: R * tr + fin, then on to its parent or its
+           sample (what k_resolve would do, without another pass over the frame); the others keep R for k_resolve. */
+        if (!(flags & (FR_C1 | FR_C2))) {
+            Spec R = have_R ? Rfin : spec_fetch(P.f_R, P.fcap, f);
+            if (flags & FR_BOUNDARY) R = R * spec_fetch(P.f_tr, P.fcap, f);
+            if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
+            frame_deliver(S, P, f, flags, R, out_rgb, out_spec);
+            flags |= FR_DONE;
+            P.f_flags[f] = flags;
+        } else {
+            if (have_R) spec_store(P.f_R, P.fcap, f, Rfin);
             P.f_flags[f] = flags;
         }
     }
@@ -570,19 +585,10 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
 }
 
 /* ------------------------------------------------------------------ k_resolve */
-__global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+/* hand a frame's finished radiance to its parent (Shade.cpp:491-501) or, for a root, to the sample:
+   Spectrum::sRGB / vRGB (RadiometryColor.h:62-66, RadiometryColor.cpp:971-983) */
+RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec)
 {
-    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= f1) return;
-    const RtDevScene &S = Sv;
-    int flags = P.f_flags[f];
-    Spec R = spec_fetch(P.f_R, P.fcap, f);
-    if (flags & FR_BOUNDARY) {
-        if (flags & FR_C1) R = R + spec_fetch(P.f_c1, P.fcap, f) * spec_fetch(P.f_w1, P.fcap, f);
-        if (flags & FR_C2) R = R + spec_fetch(P.f_c2, P.fcap, f) * P.f_geo[(size_t)GEO_W2 * P.fcap + f];
-        R = R * spec_fetch(P.f_tr, P.fcap, f);
-    }
-    if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
     int parent = P.f_parent[f];
     if (parent >= 0) {
         spec_store((flags & FR_SLOT2) ? P.f_c2 : P.f_c1, P.fcap, parent, R);
@@ -592,9 +598,9 @@ __global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, 
     if (out_spec) for (int k = 0; k < RT_NSPEC; k++) out_spec[(size_t)root * RT_NSPEC + k] = R.v[k];
     if (out_rgb) {
         float r = 0.0f, g = 0.0f, b = 0.0f;
-        if (S.venera) {                                         /* Spectrum::vRGB, RadiometryColor.cpp:971-983 */
+        if (S.venera) {
             for (int i = 0; i < RT_NSPEC; i++) { r += R.v[i] * S.chan[0][i]; g += R.v[i] * S.chan[1][i]; b += R.v[i] * S.chan[2][i]; }
-        } else {                                                /* Spectrum::sRGB, RadiometryColor.h:62-66 */
+        } else {
             for (int i = 0; i < RT_NSPEC; i++) {
                 double w = (double)R.v[i] * (5.0 / 10.0);
                 r = r + (float)((double)S.spec2rgb[i][0] * w);
@@ -604,6 +610,23 @@ __global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, 
         }
         out_rgb[(size_t)root * 3] = r; out_rgb[(size_t)root * 3 + 1] = g; out_rgb[(size_t)root * 3 + 2] = b;
     }
+}
+
+__global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+{
+    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= f1) return;
+    const RtDevScene &S = Sv;
+    int flags = P.f_flags[f];
+    if (flags & FR_DONE) return;
+    Spec R = spec_fetch(P.f_R, P.fcap, f);
+    if (flags & FR_BOUNDARY) {
+        if (flags & FR_C1) R = R + spec_fetch(P.f_c1, P.fcap, f) * spec_fetch(P.f_w1, P.fcap, f);
+        if (flags & FR_C2) R = R + spec_fetch(P.f_c2, P.fcap, f) * P.f_geo[(size_t)GEO_W2 * P.fcap + f];
+        R = R * spec_fetch(P.f_tr, P.fcap, f);
+    }
+    if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
+    frame_deliver(S, P, f, flags, R, out_rgb, out_spec);
 }
 
 /* ------------------------------------------------------------------ probe: raw hit lists */

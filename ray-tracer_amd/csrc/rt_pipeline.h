@@ -11,6 +11,7 @@
 #define FR_FINAL      16       /* MAT_NOSHADE early return: R is the result */
 #define FR_SLOT2      32       /* this frame is its parent's refraction child */
 #define FR_PERTURBED  64
+#define FR_DONE       128      /* resolved and delivered by k_shade (no reflection / refraction terms): k_resolve skips it */
 #define FR_DEPTH(f)        (((f) >> 8) & 0xFF)
 #define FR_MAKE_DEPTH(d)   (((d) & 0xFF) << 8)
 #define FR_KEEP_MASK       (0xFF00 | FR_SLOT2)
