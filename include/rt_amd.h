@@ -47,6 +47,15 @@ int  rt_render(rt_scene *s, const RtRenderDesc *rd, float *planes, RtStats *stat
    and what a multi-GPU caller gathers with RCCL. */
 int  rt_render_device(rt_scene *s, const RtRenderDesc *rd, float *planes_dev, RtStats *stats, void *hip_stream);
 
+/* Output stage -- Image::WriteBMP (Image.cpp:416-474): ClampToGamut (Image.cpp:293-327) + GammaEncode (Image.h:206-220)
+   against the table of SetGamma (Image.cpp:498-517; gamma = -1.0 is GAMMA_SRGB), 24-bit bottom-up BGR lines.
+   rt_bmp_encode: planes HOST float[3][H][W] -> the complete file image (54-byte header of WriteHeaderBMP,
+   Image.cpp:330-414, then the lines), file_bytes of rt_bmp_size(width, height) bytes.
+   rt_bmp_encode_device: planes and pixel lines (size - 54 bytes) both in DEVICE memory, no header, on `hip_stream`. */
+int64_t rt_bmp_size(int width, int height);
+int  rt_bmp_encode(const float *planes, int width, int height, double gamma, unsigned char *file_bytes, int64_t cap);
+int  rt_bmp_encode_device(const float *planes_dev, int width, int height, double gamma, unsigned char *pixels_dev, void *hip_stream);
+
 /* Host-only planning of a row-sharded render (no counterpart in the reference, which renders whole images):
    for output rows [rd->row0, rd->row1) of a FASTBLUE render, the supersample rows [out8[0], out8[1]) the vertical
    filter reads (Sampling.cpp:144-154) and the blue-noise tile rows [out8[2], out8[2] + out8[3]) whose samples can

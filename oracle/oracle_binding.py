@@ -107,3 +107,16 @@ def build_quasi_index(prime, n):
     out = np.zeros(n, dtype=np.int32)
     lib().orc_build_quasi_index(_p(out, C.c_int), prime, n)
     return out
+
+
+def bmp_encode(planes, gamma=-1.0):
+    """Image::WriteBMP restated on the CPU: the bytes of the 24-bit BMP file of a [3][H][W] float image."""
+    L = lib()
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    L.orc_bmp_encode.restype = C.c_long
+    L.orc_bmp_encode.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_ubyte), C.c_long]
+    n = L.orc_bmp_encode(_p(planes, C.c_float), w, h, gamma, None, 0)
+    out = np.zeros(n, dtype=np.uint8)
+    assert L.orc_bmp_encode(_p(planes, C.c_float), w, h, gamma, _p(out, C.c_ubyte), n) == n
+    return out

@@ -595,3 +595,83 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
     }
     return (int)ns;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Output stage: Image::WriteBMP (Image.cpp:416-474) -- SetGamma (Image.cpp:498-517), ClampToGamut
+ * (Image.cpp:293-327), GammaEncode (Image.h:206-220), WriteHeaderBMP (Image.cpp:330-414).  TEST INFRASTRUCTURE.
+ * Writes the whole 24-bit file image (54-byte header + bottom-up BGR lines padded to 4 bytes; the reference leaves
+ * the padding bytes uninitialised, here they are 0).  Returns the byte count, or the required size when out == 0. */
+static void orc_set_gamma(double gamma, float *T, float *A)
+{
+    for (int n = 0; n < 256; n++) {
+        if (gamma == -1.0) {                         /* GAMMA_SRGB, Image.h:21 */
+            double f = (double)n * (1.0 / 255.0);
+            if (f <= 0.03928) f = f / 12.92;
+            else f = (float)pow((f + 0.055) / 1.055, 2.4);
+            T[n] = (float)f;
+        } else
+            T[n] = (float)pow((double)n * (1.0 / 255.0), gamma);
+    }
+    A[0] = 0.0f;
+    for (int n = 1; n < 256; n++) A[n] = (T[n - 1] + T[n]) / 2;
+}
+static int orc_gamma_encode(const float *A, double f)
+{
+    int n = 0;
+    if (f > A[128]) n = 128;
+    if (f > A[n + 64]) n = n + 64;
+    if (f > A[n + 32]) n = n + 32;
+    if (f > A[n + 16]) n = n + 16;
+    if (f > A[n + 8]) n = n + 8;
+    if (f > A[n + 4]) n = n + 4;
+    if (f > A[n + 2]) n = n + 2;
+    if (f > A[n + 1]) n = n + 1;
+    return n;
+}
+static void orc_clamp_to_gamut(float &red, float &grn, float &blu)
+{
+    float fLum = 0.2126f * red + 0.7152f * grn + 0.0722f * blu, t;      /* Luminance(), Image.h:110-115 */
+    if (fLum < 0.0) { red = grn = blu = 0.0f; return; }
+    if (fLum > 1.0) { red = grn = blu = 1.0f; return; }
+    t = 1.0;
+    if (red < 0.0 && -fLum > (red - fLum) * t) t = -fLum / (red - fLum);
+    if (red > 1.0 && 1.0 - fLum < (red - fLum) * t) t = (1.0f - fLum) / (red - fLum);
+    if (grn < 0.0 && -fLum > (grn - fLum) * t) t = -fLum / (grn - fLum);
+    if (grn > 1.0 && 1.0 - fLum < (grn - fLum) * t) t = (1.0f - fLum) / (grn - fLum);
+    if (blu < 0.0 && -fLum > (blu - fLum) * t) t = -fLum / (blu - fLum);
+    if (blu > 1.0 && 1.0 - fLum < (blu - fLum) * t) t = (1.0f - fLum) / (blu - fLum);
+    float r = fLum + t * (red - fLum), g = fLum + t * (grn - fLum), b = fLum + t * (blu - fLum);
+    red = r; grn = g; blu = b;
+}
+extern "C" long orc_bmp_encode(const float *planes, int width, int height, double gamma, unsigned char *out, long cap)
+{
+    long line = 4 * ((24L * width + 31) >> 5), total = 54 + line * height;
+    if (!out) return total;
+    if (cap < total) return -1;
+    memset(out, 0, (size_t)total);
+    out[0] = 'B'; out[1] = 'M';
+    uint32_t h32[13];
+    h32[0] = (uint32_t)total;           /* bfSize */
+    h32[1] = 0;                         /* bfReserved1/2 */
+    h32[2] = 54;                        /* bfOffBits */
+    h32[3] = 40; h32[4] = (uint32_t)width; h32[5] = (uint32_t)height;
+    h32[6] = 1u | (24u << 16);          /* biPlanes, biBitCount */
+    h32[7] = 0; h32[8] = 0;
+    h32[9] = h32[10] = (uint32_t)(int)(300.0 / 0.0254 + 0.5);
+    h32[11] = 0; h32[12] = 0;
+    memcpy(out + 2, h32, sizeof h32);
+    float T[256], A[256];
+    orc_set_gamma(gamma, T, A);
+    const size_t plane = (size_t)width * height;
+    for (int j = height - 1, row = 0; j >= 0; --j, ++row) {
+        unsigned char *p = out + 54 + (size_t)row * line;
+        for (int i = 0; i < width; i++) {
+            float r = planes[(size_t)j * width + i], g = planes[plane + (size_t)j * width + i], b = planes[2 * plane + (size_t)j * width + i];
+            if (r < 0.0 || r > 1.0 || g < 0.0 || g > 1.0 || b < 0.0 || b > 1.0) orc_clamp_to_gamut(r, g, b);
+            p[3 * i + 0] = (unsigned char)orc_gamma_encode(A, b);
+            p[3 * i + 1] = (unsigned char)orc_gamma_encode(A, g);
+            p[3 * i + 2] = (unsigned char)orc_gamma_encode(A, r);
+        }
+    }
+    return total;
+}

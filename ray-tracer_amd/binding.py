@@ -228,3 +228,19 @@ def build_quasi_index(prime, n):
     out = np.zeros(n, dtype=np.int32)
     rt_lib().rt_build_quasi_index(_p(out, C.c_int), prime, n)
     return out
+
+
+def bmp_encode(planes, gamma=-1.0):
+    """Image::WriteBMP on the GPU (rt_bmp_encode): the bytes of the 24-bit BMP file of a [3][H][W] float image."""
+    L = rt_lib()
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    L.rt_bmp_size.restype = C.c_int64
+    L.rt_bmp_size.argtypes = [C.c_int, C.c_int]
+    L.rt_bmp_encode.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_ubyte), C.c_int64]
+    n = L.rt_bmp_size(w, h)
+    out = np.zeros(n, dtype=np.uint8)
+    rc = L.rt_bmp_encode(planes.ctypes.data_as(C.POINTER(C.c_float)), w, h, float(gamma), out.ctypes.data_as(C.POINTER(C.c_ubyte)), n)
+    if rc:
+        raise RtError("rt_bmp_encode: %s" % L.rt_last_error().decode())
+    return out

@@ -869,4 +869,54 @@ __global__ void __launch_bounds__(256) k_store_test(const float *sample_rgb, int
     for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] = c[k];
 }
 
+/* ------------------------------------------------------------------ output stage: Image::WriteBMP, Image.cpp:416-474
+ * One thread per pixel: ClampToGamut (Image.cpp:293-327) when a channel leaves [0,1], then GammaEncode's
+ * eight-step search (Image.h:206-220) of the 255 thresholds SetGamma built (host, Image.cpp:498-517), written as
+ * bottom-up BGR lines of `line` bytes.  Comparisons and float arithmetic only: byte-exact against the CPU. */
+struct RtGammaTable { float a[256]; };
+RT_DEV int gamma_encode(const float *A, double f)
+{
+    int n = 0;
+    if (f > A[128]) n = 128;
+    if (f > A[n + 64]) n = n + 64;
+    if (f > A[n + 32]) n = n + 32;
+    if (f > A[n + 16]) n = n + 16;
+    if (f > A[n + 8]) n = n + 8;
+    if (f > A[n + 4]) n = n + 4;
+    if (f > A[n + 2]) n = n + 2;
+    if (f > A[n + 1]) n = n + 1;
+    return n;
+}
+__global__ void __launch_bounds__(256) k_bmp_encode(const float *planes, int width, int height, RtGammaTable G, int line, unsigned char *pixels)
+{
+    __shared__ float A[256];
+    A[threadIdx.x] = G.a[threadIdx.x];
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (i >= width) return;
+    int j = height - 1 - row;
+    size_t plane = (size_t)width * height, o = (size_t)j * width + i;
+    float red = planes[o], grn = planes[plane + o], blu = planes[2 * plane + o];
+    if (red < 0.0 || red > 1.0 || grn < 0.0 || grn > 1.0 || blu < 0.0 || blu > 1.0) {
+        float fLum = 0.2126f * red + 0.7152f * grn + 0.0722f * blu, t;      /* Luminance(), Image.h:110-115 */
+        if (fLum < 0.0) red = grn = blu = 0.0f;
+        else if (fLum > 1.0) red = grn = blu = 1.0f;
+        else {
+            t = 1.0;
+            if (red < 0.0 && -fLum > (red - fLum) * t) t = -fLum / (red - fLum);
+            if (red > 1.0 && 1.0 - fLum < (red - fLum) * t) t = (1.0f - fLum) / (red - fLum);
+            if (grn < 0.0 && -fLum > (grn - fLum) * t) t = -fLum / (grn - fLum);
+            if (grn > 1.0 && 1.0 - fLum < (grn - fLum) * t) t = (1.0f - fLum) / (grn - fLum);
+            if (blu < 0.0 && -fLum > (blu - fLum) * t) t = -fLum / (blu - fLum);
+            if (blu > 1.0 && 1.0 - fLum < (blu - fLum) * t) t = (1.0f - fLum) / (blu - fLum);
+            float r = fLum + t * (red - fLum), g = fLum + t * (grn - fLum), b = fLum + t * (blu - fLum);
+            red = r; grn = g; blu = b;
+        }
+    }
+    unsigned char *p = pixels + (size_t)row * line + 3 * (size_t)i;
+    p[0] = (unsigned char)gamma_encode(A, blu);
+    p[1] = (unsigned char)gamma_encode(A, grn);
+    p[2] = (unsigned char)gamma_encode(A, red);
+}
+
 #include "rt_api.inc"

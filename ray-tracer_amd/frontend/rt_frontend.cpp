@@ -694,6 +694,19 @@ int Image::NewImage(int w, int h, int channels)
     return m_pfImage != 0;
 }
 
+int Image::WriteBMP(const char *szFileName, double fGamma)
+{
+    if (m_pfImage == 0 || m_nChannels != 3) return 0;
+    int64_t n = rt_bmp_size(m_nWidth, m_nHeight);
+    std::vector<unsigned char> bytes((size_t)n);
+    if (rt_bmp_encode(m_pfImage, m_nWidth, m_nHeight, fGamma, &bytes[0], n)) { snprintf(s_err, sizeof s_err, "rt_bmp_encode: %s", rt_last_error()); return 0; }
+    FILE *pf = fopen(szFileName, "wb");
+    if (!pf) return 0;
+    size_t w = fwrite(&bytes[0], 1, (size_t)n, pf);
+    fclose(pf);
+    return w == (size_t)n ? 1 : 0;
+}
+
 int RayTracer::Render(Image &im, double spp)
 {
     RtSceneBlob blob;

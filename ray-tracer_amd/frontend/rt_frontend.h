@@ -180,6 +180,9 @@ struct Image {
     int NewImage(int w, int h, int channels = 1);
     float Get(int i, int j, int k = 0) const { return m_pfImage[i + m_nWidth * (int64_t)(j + m_nHeight * k)]; }
     DisplayRGB GetRGB(int i, int j) const { return DisplayRGB(Get(i, j, 0), Get(i, j, 1), Get(i, j, 2)); }
+    /* Image::WriteBMP (Image.cpp:416-474), 3-channel images: clamp to gamut + gamma-encode on the GPU (rt_bmp_encode),
+       then the file is written here.  Returns 1, or 0 on error like the reference. */
+    int WriteBMP(const char *szFileName, double fGamma = -1.0 /* GAMMA_SRGB */);
 private:
     Image(const Image &);
     Image &operator=(const Image &);

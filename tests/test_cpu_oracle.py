@@ -158,3 +158,25 @@ def test_upload_without_gpu_fails_loudly(rt):
     with pytest.raises(rt.RtError) as e:
         rt.GpuScene(fs.desc)
     assert "no HIP device" in str(e.value) or "CPU path" in str(e.value)
+
+
+def test_bmp_restatement_layout_and_gamma(oracle):
+    """Image::WriteBMP restated: header fields (Image.cpp:330-414), bottom-up BGR lines padded to 4 bytes, and the
+    sRGB encode table: 0 -> 0, 1 -> 255, monotone, every code used, linear 0.2140 = ((0.5 + 0.055)/1.055)^2.4 -> 127 or 128."""
+    import struct
+    img = np.zeros((3, 2, 3), dtype=np.float32)
+    img[0, 0, 0] = 1.0          # red, top-left
+    img[2, 1, 2] = 1.0          # blue, bottom-right
+    b = oracle.bmp_encode(img)
+    assert len(b) == 54 + 2 * 12 and b[:2].tobytes() == b"BM"
+    size, _, off, hdr, w, h, planes, bits = struct.unpack("<IIIIIIHH", b[2:30].tobytes())
+    assert (size, off, hdr, w, h, planes, bits) == (78, 54, 40, 3, 2, 1, 24)
+    assert struct.unpack("<II", b[38:46].tobytes()) == (11811, 11811)          # 300 dpi
+    first_line, second_line = b[54:66], b[66:78]
+    assert list(first_line[6:9]) == [255, 0, 0] and list(second_line[0:3]) == [0, 0, 255]      # file line 0 = image row 1
+    assert list(first_line[9:12]) == [0, 0, 0]                                                  # padding
+    ramp = np.linspace(0.0, 1.0, 4096, dtype=np.float32)
+    enc = oracle.bmp_encode(np.stack([ramp.reshape(1, -1)] * 3))[54:54 + 3 * 4096:3]
+    assert enc[0] == 0 and enc[-1] == 255 and np.all(np.diff(enc.astype(int)) >= 0) and len(set(enc.tolist())) == 256
+    grey = np.full((3, 1, 4), 0.2140, dtype=np.float32)
+    assert oracle.bmp_encode(grey)[54] in (127, 128)

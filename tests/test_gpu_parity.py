@@ -269,3 +269,17 @@ def test_long_hit_lists_compact_the_arena(gpu, oracle):
     assert np.array_equal(gc, oc) and np.array_equal(gl, ol) and np.array_equal(gm, om) and np.array_equal(gs, osf)
     assert np.array_equal(gt, ot) and np.array_equal(gn, on)
     assert np.array_equal(g.radiance(org, dr), o.radiance(org, dr))
+
+
+def test_bmp_output_stage_is_byte_exact(gpu, oracle):
+    """8f-2 output stage: ClampToGamut + GammaEncode + BMP layout on the GPU give the bytes of the CPU restatement,
+    for a rendered frame, for values far outside the gamut and for a width that needs line padding."""
+    fs = gpu.FrontScene("S1", "fastblue", optimize=True)
+    img, _ = gpu.GpuScene(fs.desc).render(96, 64, 4)
+    assert np.array_equal(gpu.bmp_encode(img), oracle.bmp_encode(img))
+    rng = np.random.default_rng(11)
+    wild = rng.normal(0.5, 1.0, (3, 37, 53)).astype(np.float32)         # 53 * 3 = 159 bytes: one byte of padding per line
+    wild[:, 0, :8] = np.array([[-1, 0, 1, 2, np.inf, -np.inf, 1e-9, 0.5]] * 3, dtype=np.float32)
+    for gamma in (-1.0, 2.2, 1.0):
+        a, b = gpu.bmp_encode(wild, gamma), oracle.bmp_encode(wild, gamma)
+        assert a[:2].tobytes() == b"BM" and np.array_equal(a, b), gamma
