@@ -90,6 +90,8 @@ int  rt_probe_sample_rgb(rt_scene *s, const RtRenderDesc *rd, float *out_rgb, in
 /* BuildQuasiIndex (Patterns.cpp:1723-1736), RandomUnsigned (MonteCarlo.h:17-27): host-side integer helpers. */
 void rt_build_quasi_index(int *out, int prime, int n);
 void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);
+/* the state after ndraws calls of RandomUnsigned, without making them (what a render with JitterSamplingTile leaves behind) */
+void rt_random_skip(uint32_t state_xc[2], uint64_t ndraws);
 
 /* Measurement support for bench.py (no counterpart in the reference): sums, over those of the n rays that reach
    k_visual (rays that miss every box of the scene end in the generation kernel), of the ideal-culling event

@@ -88,14 +88,16 @@ typedef struct RtCamera {       /* Cameras.h:8-67 */
     double  focus_distance;
 } RtCamera;
 
-enum RtSamplerType { RT_SAMPLER_TEST = 0, RT_SAMPLER_FASTBLUE = 1 };
+enum RtSamplerType { RT_SAMPLER_TEST = 0, RT_SAMPLER_FASTBLUE = 1, RT_SAMPLER_JITTER = 2 };
 typedef struct RtSampler {      /* Sampling.h; Sampling.cpp:324-348, 474-548 */
     int32_t type;
     int32_t venera;             /* nVenera: vRGB instead of sRGB */
     const int32_t *qindex2;     /* g_BlueNoiseQuasiIndex2 as left by QIndex1() -- RT_BLUE_N ints (FASTBLUE only) */
     const int32_t *qindex3;     /* g_BlueNoiseQuasiIndex3 -- RT_BLUE_N ints (FASTBLUE only) */
     double  aux_init[6];        /* g_uCamera,g_vCamera,g_uLight,g_vLight,g_uMicroFacet,g_vMicroFacet as they stand
-                                   when a sampler that never writes them (TestSamplingTile) runs */
+                                   when a sampler that never writes them (TestSamplingTile, JitterSamplingTile) runs */
+    uint32_t prng_x, prng_c;    /* ML_nMarsagliaX, ML_nMarsagliaC (MonteCarlo.cpp:9-10) as they stand when Render is called:
+                                   JitterSamplingTile draws its sample positions from that stream (Sampling.cpp:407-408) */
 } RtSampler;
 
 typedef struct RtSceneDesc {

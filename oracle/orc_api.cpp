@@ -219,6 +219,7 @@ extern "C" void *orc_scene_create(const RtSceneDesc *d, int run_optimize)
     if (d->sampler.qindex2) s->qi2.assign(d->sampler.qindex2, d->sampler.qindex2 + RT_BLUE_N);
     if (d->sampler.qindex3) s->qi3.assign(d->sampler.qindex3, d->sampler.qindex3 + RT_BLUE_N);
     for (int i = 0; i < 6; i++) s->aux_init[i] = d->sampler.aux_init[i];
+    s->prng_x = d->sampler.prng_x; s->prng_c = d->sampler.prng_c;
     return s;
 }
 
@@ -510,6 +511,27 @@ extern "C" long orc_fastblue_samples(void *h, int width, int height, double spp,
     return total;
 }
 
+/* JitterSamplingTile sample positions (Sampling.cpp:404-408) in loop order: out2 = (vx, vy) normalised */
+extern "C" long orc_jitter_samples(void *h, int width, int height, double spp, long first, long n, double *out2)
+{
+    Scene *s = (Scene *)h;
+    int nn = int(width * sqrt(spp) + 0.5), nHi = int(height * sqrt(spp) + 0.5);
+    uint32_t px = s->prng_x, pc = s->prng_c;
+    auto draw = [&]() -> double {
+        uint64_t a = (uint64_t)1965537969u * px + pc; px = (uint32_t)a; pc = (uint32_t)(a >> 32); uint32_t hi = px;
+        a = (uint64_t)1965537969u * px + pc; px = (uint32_t)a; pc = (uint32_t)(a >> 32); uint32_t lo = px;
+        return (double(hi) + double(lo) * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0);
+    };
+    long idx = 0;
+    for (int j = 0; j < nHi; j++)
+        for (int i = 0; i < nn; i++, idx++) {
+            double vy = (double(j) + (nn - nHi) / 2 + draw()) / double(nn);
+            double vx = (double(i) + draw()) / double(nn);
+            if (idx >= first && idx < first + n && out2) { out2[2 * (idx - first)] = vx; out2[2 * (idx - first) + 1] = vy; }
+        }
+    return idx;
+}
+
 /* RayTracer::Render (RayTracer2020.cpp:33-38) through TestSamplingTile (Sampling.cpp:324-348) or
    FastBlueSamplingTile (Sampling.cpp:474-533).  planes: float[3][H][W].  sample_rgb (optional):
    per-sample RGB in loop order.  threads > 1 evaluates samples in parallel (the image function is
@@ -544,6 +566,47 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
                 if (sample_rgb_out) { float *o = sample_rgb_out + 3 * ((size_t)j * W + i); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
             }
         ns = (long)W * H;
+    } else if (s->sampler_type == RT_SAMPLER_JITTER) {
+        /* JitterSamplingTile::Render, Sampling.cpp:394-419: one sample per supersample pixel at a random position drawn
+           from the global MWC stream (y before x, RandomDouble = two RandomUnsigned, high word first), SetRGB, then
+           ImageResample without weights.  The draws are made serially in the reference's order; only the radiance
+           evaluation is spread over threads. */
+        double spp = rd->spp;
+        int n = int(W * sqrt(spp) + 0.5), nHi = int(H * sqrt(spp) + 0.5);
+        std::vector<double> vxs((size_t)n * nHi), vys((size_t)n * nHi);
+        uint32_t px = s->prng_x, pc = s->prng_c;
+        auto draw = [&]() -> double {
+            uint64_t a = (uint64_t)1965537969u * px + pc; px = (uint32_t)a; pc = (uint32_t)(a >> 32); uint32_t hi = px;
+            a = (uint64_t)1965537969u * px + pc; px = (uint32_t)a; pc = (uint32_t)(a >> 32); uint32_t lo = px;
+            return (double(hi) + double(lo) * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0);
+        };
+        for (int j = 0; j < nHi; j++)
+            for (int i = 0; i < n; i++) {
+                vys[(size_t)j * n + i] = (double(j) + (n - nHi) / 2 + draw()) / double(n);
+                vxs[(size_t)j * n + i] = (double(i) + draw()) / double(n);
+            }
+        Img im2;
+        im2.alloc(n, nHi, 3);
+        std::vector<Rgb> rgb((size_t)n * nHi);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(+:np,nsh,nsec)
+        for (int j = 0; j < nHi; j++) {
+            Ctx cx;
+            for (int k = 0; k < 6; k++) cx.aux[k] = s->aux_init[k];
+            for (int i = 0; i < n; i++) rgb[(size_t)j * n + i] = sample_rgb(*s, vxs[(size_t)j * n + i], vys[(size_t)j * n + i], cx);
+            np += cx.n_primary; nsh += cx.n_shadow; nsec += cx.n_secondary;
+        }
+        for (int j = 0; j < nHi; j++)
+            for (int i = 0; i < n; i++) {
+                const Rgb &c = rgb[(size_t)j * n + i];
+                im2.px[(size_t)i + (size_t)n * (j + (size_t)nHi * 0)] = c.r;
+                im2.px[(size_t)i + (size_t)n * (j + (size_t)nHi * 1)] = c.g;
+                im2.px[(size_t)i + (size_t)n * (j + (size_t)nHi * 2)] = c.b;
+            }
+        ns = (long)n * nHi;
+        if (sample_rgb_out) memcpy(sample_rgb_out, &rgb[0], sizeof(Rgb) * rgb.size());
+        Img im;
+        image_resample(im, W, H, im2);
+        memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
     } else {
         double spp = rd->spp;
         int nW = int(W * sqrt(spp) + 0.5), nH = int(H * sqrt(spp) + 0.5);

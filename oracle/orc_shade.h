@@ -23,7 +23,8 @@ struct Scene {
     int     sampler_type, venera;
     std::vector<int> qi2, qi3;
     double  aux_init[6];
-    Scene() : root(0), has_ambient(false), sampler_type(0), venera(0) {}
+    uint32_t prng_x, prng_c;    /* MWC state at Render time (JitterSamplingTile) */
+    Scene() : root(0), has_ambient(false), sampler_type(0), venera(0), prng_x(886459), prng_c(361290869) {}
     ~Scene() { for (size_t i = 0; i < nodes.size(); i++) delete nodes[i]; }
 };
 

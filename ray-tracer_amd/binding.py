@@ -10,7 +10,7 @@ LIB_RT = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")   # 
 LIB_FRONTEND = os.path.join(HERE, "librt_frontend.so")
 TABLES = os.path.join(HERE, "data", "tables.bin")
 NSPEC = 10
-RT_SAMPLER_TEST, RT_SAMPLER_FASTBLUE = 0, 1      # enum RtSamplerType, include/rt_scene_desc.h
+RT_SAMPLER_TEST, RT_SAMPLER_FASTBLUE, RT_SAMPLER_JITTER = 0, 1, 2      # enum RtSamplerType, include/rt_scene_desc.h
 BLUE_N = 1600
 
 
@@ -32,7 +32,7 @@ class RtCamera(C.Structure):
 
 class RtSampler(C.Structure):
     _fields_ = [("type", C.c_int32), ("venera", C.c_int32), ("qindex2", C.POINTER(C.c_int32)),
-                ("qindex3", C.POINTER(C.c_int32)), ("aux_init", C.c_double * 6)]
+                ("qindex3", C.POINTER(C.c_int32)), ("aux_init", C.c_double * 6), ("prng_x", C.c_uint32), ("prng_c", C.c_uint32)]
 
 
 class RtSceneDesc(C.Structure):

@@ -39,3 +39,25 @@ extern "C" void rt_random_unsigned(uint32_t st[2], int n, uint32_t *out)
     }
     st[0] = x; st[1] = c;
 }
+
+
+/* The multiply-with-carry generator of MonteCarlo.h:17-27, x' = (a x + c) mod 2^32, c' = (a x + c) >> 32 with
+   a = 1965537969, is multiplication by a modulo m = a 2^32 - 1 of the combined state s = c 2^32 + x
+   (a 2^32 = 1 mod m, so a s = a x + c 2^32 a = a x + c).  n draws ahead is therefore s a^n mod m. */
+static const unsigned __int128 kMwcA = 1965537969u;
+static inline uint64_t mwc_modulus() { return (uint64_t)((kMwcA << 32) - 1); }
+static inline uint64_t mwc_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % mwc_modulus()); }
+uint64_t rt_mwc_power(uint64_t n)
+{
+    uint64_t r = 1, b = (uint64_t)kMwcA;
+    for (; n; n >>= 1) { if (n & 1) r = mwc_mulmod(r, b); b = mwc_mulmod(b, b); }
+    return r;
+}
+uint64_t rt_mwc_jump(uint64_t state, uint64_t power) { return mwc_mulmod(state, power); }
+
+extern "C" void rt_random_skip(uint32_t state_xc[2], uint64_t ndraws)
+{
+    uint64_t s = ((uint64_t)state_xc[1] << 32) | state_xc[0];
+    s = rt_mwc_jump(s, rt_mwc_power(ndraws));
+    state_xc[0] = (uint32_t)s; state_xc[1] = (uint32_t)(s >> 32);
+}

@@ -59,6 +59,24 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
         for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
         return;
     }
+    if (g.sampler == RT_SAMPLER_JITTER) {               /* JitterSamplingTile::Render, Sampling.cpp:404-413 */
+        const int n = g.nW, nHi = g.nH;
+        const int jl = (int)(s / n), i = (int)(s - (int64_t)jl * n), j = g.jit_row0 + jl;
+        /* the reference draws four RandomUnsigned per sample from one global stream (MonteCarlo.h:17-40), row by
+           row; the host provides the stream's state at every 64th pixel (rt_random_skip arithmetic) and the lane
+           steps from there */
+        const uint32_t *stp = g.jit_states + 2 * ((size_t)jl * g.jit_segs + (i >> 6));
+        uint32_t x = stp[0], c = stp[1], u[4];
+        for (int k = 4 * (i & 63); k > 0; --k) { uint64_t a = (uint64_t)1965537969u * x + c; x = (uint32_t)a; c = (uint32_t)(a >> 32); }
+        for (int k = 0; k < 4; k++) { uint64_t a = (uint64_t)1965537969u * x + c; x = (uint32_t)a; c = (uint32_t)(a >> 32); u[k] = x; }
+        const double ry = ((double)u[0] + (double)u[1] * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0);
+        const double rx = ((double)u[2] + (double)u[3] * (1.0 / 4294967296.0)) * (1.0 / 4294967296.0);
+        v2[1] = ((double)j + (double)((n - nHi) / 2) + ry) / (double)n;
+        v2[0] = ((double)i + rx) / (double)n;
+        pos2[0] = (double)i; pos2[1] = (double)j;
+        for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
+        return;
+    }
     /* FastBlueSamplingTile::Render, Sampling.cpp:498-517: tile x outer, tile y inner, i innermost */
     const uint32_t tile = (uint32_t)(s / RT_BLUE_N);      /* < 2^31 tiles (checked by the host) */
     int i = (int)(s - (int64_t)tile * RT_BLUE_N);
@@ -867,6 +885,15 @@ __global__ void __launch_bounds__(256) k_store_test(const float *sample_rgb, int
     if (i >= width || j >= row1) return;
     const float *c = sample_rgb + 3 * ((size_t)(j - row0) * width + i);
     for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] = c[k];
+}
+
+/* JitterSamplingTile: im2.SetRGB(rad.sRGB(), i, j) (Sampling.cpp:412): per-sample RGB in row-major sample order -> planes */
+__global__ void __launch_bounds__(256) k_store_jitter(const float *sample_rgb, int nW, int rows, float *im2 /*[3][rows][nW]*/)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
+    if (i >= nW) return;
+    size_t o = (size_t)jl * nW + i, plane = (size_t)rows * nW;
+    im2[o] = sample_rgb[3 * o]; im2[plane + o] = sample_rgb[3 * o + 1]; im2[2 * plane + o] = sample_rgb[3 * o + 2];
 }
 
 /* ------------------------------------------------------------------ output stage: Image::WriteBMP, Image.cpp:416-474

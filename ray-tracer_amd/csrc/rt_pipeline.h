@@ -48,6 +48,9 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     int     tiles_x, tiles_y;   /* 40x40 blue-noise tiles covering it, Sampling.cpp:498-499 */
     int     tile_y0, tiles_y_local;     /* tile rows traced by this call (row sharding) */
     int     test_row0, test_rows;       /* TEST sampler: output rows traced by this call */
+    int     jit_row0, jit_rows;         /* JITTER sampler: supersample rows traced by this call */
+    int     jit_segs;                   /* JITTER: 64-pixel segments per supersample row */
+    const uint32_t *jit_states;         /* JITTER: MWC state (x, c) at the start of every segment of the traced rows */
     int     pad_;
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */

@@ -683,6 +683,7 @@ int rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen)
     d.sampler.qindex3 = &out.qi3[0];
     const double aux[6] = { g_uCamera, g_vCamera, g_uLight, g_vLight, g_uMicroFacet, g_vMicroFacet };
     memcpy(d.sampler.aux_init, aux, sizeof aux);
+    d.sampler.prng_x = ML_nMarsagliaX; d.sampler.prng_c = ML_nMarsagliaC;
     return 0;
 }
 
@@ -720,5 +721,10 @@ int RayTracer::Render(Image &im, double spp)
     int rc = rt_render(sc, &rd, im.m_pfImage, &stats);
     if (rc) snprintf(s_err, sizeof s_err, "rt_render: %s", rt_last_error());
     rt_scene_free(sc);
+    if (!rc && blob.desc.sampler.type == RT_SAMPLER_JITTER) {      /* the tile consumed four RandomUnsigned per sample */
+        uint32_t st[2] = { ML_nMarsagliaX, ML_nMarsagliaC };
+        rt_random_skip(st, 4ull * (uint64_t)stats.samples);
+        ML_nMarsagliaX = st[0]; ML_nMarsagliaC = st[1];
+    }
     return rc ? -1 : (int)stats.samples;
 }

@@ -508,6 +508,8 @@ struct SamplingTile {
     virtual int  DeviceSampler() const = 0;     /* RtSamplerType, -1 if this tile has no device path yet */
 };
 struct TestSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_TEST; } };
+/* JitterSamplingTile (Sampling.cpp:388-419): one sample per supersample pixel, jittered by the global MWC stream */
+struct JitterSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_JITTER; } };
 struct FastBlueSamplingTile : SamplingTile {
     FastBlueSamplingTile() { nVenera = 0; }
     void QIndex1(int prime);

@@ -370,6 +370,7 @@ struct Parser {
             else if (w == "sampler") {
                 std::string k = word();
                 if (k == "test") rt->psSample = new TestSamplingTile;
+                else if (k == "jitter") rt->psSample = new JitterSamplingTile;
                 else if (k == "fastblue") { rt->psSample = new FastBlueSamplingTile; if (!peek_close()) rt->psSample->QIndex1((int)num()); }
                 else fail("unknown sampler " + k);
             }
@@ -391,7 +392,7 @@ static char s_scene_err[512];
 
 extern "C" const char *rtf_last_error() { return s_scene_err[0] ? s_scene_err : rt_frontend_last_error(); }
 
-/* spec: "S0" | "S1" | "S2" | "(scene ...)".  sampler: "", "test" or "fastblue" overrides the scene's tile.
+/* spec: "S0" | "S1" | "S2" | "(scene ...)".  sampler: "", "test", "jitter" or "fastblue" overrides the scene's tile.
    optimize != 0 calls psModel->Optimize() before flattening (what every reference driver does). */
 extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int optimize)
 {
@@ -410,6 +411,7 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     }
     if (rc) { delete s; return 0; }
     if (sampler && !strcmp(sampler, "test")) s->rt.psSample = new TestSamplingTile;
+    else if (sampler && !strcmp(sampler, "jitter")) s->rt.psSample = new JitterSamplingTile;
     else if (sampler && !strcmp(sampler, "fastblue") && !(s->rt.psSample && s->rt.psSample->DeviceSampler() == RT_SAMPLER_FASTBLUE)) s->rt.psSample = new FastBlueSamplingTile;
     if (!s->rt.psSample) s->rt.psSample = new TestSamplingTile;
     if (!s->rt.pcCamera) s->rt.pcCamera = new StereographicCamera(Point3(0.0, 0.0, 8.0), 70.0);

@@ -180,3 +180,38 @@ def test_bmp_restatement_layout_and_gamma(oracle):
     assert enc[0] == 0 and enc[-1] == 255 and np.all(np.diff(enc.astype(int)) >= 0) and len(set(enc.tolist())) == 256
     grey = np.full((3, 1, 4), 0.2140, dtype=np.float32)
     assert oracle.bmp_encode(grey)[54] in (127, 128)
+
+
+def test_random_skip_equals_stepping(rt):
+    """rt_random_skip (MWC as multiplication by a modulo a 2^32 - 1) lands where RandomUnsigned would after n draws."""
+    import ctypes as C
+    L = rt.rt_lib()
+    L.rt_random_skip.argtypes = [C.POINTER(C.c_uint32), C.c_uint64]
+    L.rt_random_unsigned.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
+    for n in (0, 1, 2, 255, 256, 100003):
+        a = (C.c_uint32 * 2)(886459, 361290869)
+        b = (C.c_uint32 * 2)(886459, 361290869)
+        out = (C.c_uint32 * max(n, 1))()
+        L.rt_random_unsigned(a, n, out)
+        L.rt_random_skip(b, n)
+        assert (a[0], a[1]) == (b[0], b[1]), n
+
+
+def test_jitter_tile_restatement(rt, oracle):
+    """JitterSamplingTile: one sample per supersample pixel inside its own pixel, y drawn before x, and an image that
+    agrees with the blue-noise tile's up to sampling noise."""
+    raw = rt.FrontScene("S0", "jitter", optimize=False)
+    osc = oracle.OracleScene(raw.desc)
+    v, tot = osc.jitter_samples(40, 24, 4, 0, 80 * 48)
+    assert tot == 80 * 48
+    i = np.arange(tot) % 80
+    j = np.arange(tot) // 80
+    assert np.all((v[:, 0] * 80 >= i) & (v[:, 0] * 80 < i + 1))
+    assert np.all((v[:, 1] * 80 - (80 - 48) // 2 >= j) & (v[:, 1] * 80 - (80 - 48) // 2 < j + 1))
+    rd = rt.RtRenderDesc(40, 24, 4.0, 0, 0)
+    a, _, n = osc.render(40, 24, 4, rd, rt.RtStats(), threads=2)
+    assert n == tot
+    fbs = rt.FrontScene("S0", "fastblue", optimize=False)      # keep it alive: the description points into it
+    fb = oracle.OracleScene(fbs.desc)
+    b, _, _ = fb.render(40, 24, 4, rd, rt.RtStats(), threads=2)
+    assert np.abs(a - b).mean() < 0.02 and np.abs(a).mean() > 0.001

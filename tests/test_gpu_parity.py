@@ -283,3 +283,26 @@ def test_bmp_output_stage_is_byte_exact(gpu, oracle):
     for gamma in (-1.0, 2.2, 1.0):
         a, b = gpu.bmp_encode(wild, gamma), oracle.bmp_encode(wild, gamma)
         assert a[:2].tobytes() == b"BM" and np.array_equal(a, b), gamma
+
+
+@pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 2e-5)])
+def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
+    """a1 JitterSamplingTile (Sampling.cpp:394-419): sample positions from the MWC stream (skip-ahead on the host,
+    stepping on the device) bit exact, image equal to the oracle's (exact where no libm call is on the path), a band
+    rendered on its own equal to the same rows of the frame."""
+    opt, raw, g, o = _pair(gpu, oracle, scene, "jitter")
+    w, h, spp = 100, 60, 9
+    s8, xy, tot = g.samples(w, h, spp, 0, 300 * 180)
+    v, tot2 = o.jitter_samples(w, h, spp, 0, 300 * 180)
+    assert tot == tot2 == 300 * 180 and np.array_equal(s8[:, :2], v)
+    img, st = g.render(w, h, spp)
+    rd = gpu.RtRenderDesc(w, h, float(spp), 0, 0)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(w, h, spp, rd, ost, threads=4)
+    assert st.samples == n and st.rays() == ost.rays()
+    if tol == 0.0:
+        assert np.array_equal(img, ref)
+    else:
+        assert np.abs(img - ref).max() <= tol
+    band, _ = g.render(w, h, spp, row0=17, row1=41)
+    assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
