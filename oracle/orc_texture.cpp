@@ -103,6 +103,31 @@ float gradient_band_noise(float *g, const float *p, int ndim)
     return v;
 }
 
+/* GradientFractalNoise, Texture.cpp:243-297, with the defaults of Texture.h:19-21 (fractal dimension 1, lacunarity 2.1,
+   no absolute value) and a whole number of levels (every caller passes 5 or 6, so the remainder branch never runs) */
+float gradient_fractal_noise(float *grad, const float *p, int ndim, int levels)
+{
+    const float lac = 2.1f;
+    float omega = powf(lac, -1.0f);
+    float wl = 1.0f, scale = 1.0f, noise = 0.0f, gain = 0.0f, sc[3] = { 0, 0, 0 }, bg[3] = { 0, 0, 0 };
+    for (int j = 0; j < ndim; j++) { sc[j] = p[j]; grad[j] = 0.0f; }
+    for (int i = 0; i < levels; i++) {
+        float fb = wl * (gradient_band_noise(bg, sc, ndim) - 0.5f);
+        float sign = 1.0f;
+        noise += fb;
+        for (int j = 0; j < ndim; j++) {
+            sc[j] *= lac;
+            grad[j] += bg[j] * scale * wl * sign;
+        }
+        gain += wl;
+        wl *= omega;
+        scale *= lac;
+    }
+    gain = 1.0f / gain;
+    for (int j = 0; j < ndim; j++) grad[j] *= gain;
+    return noise * gain + 0.5f;
+}
+
 /* TextureMaps.cpp:189-198 */
 static void perturb(Hit &h, const V3 &d)
 {
@@ -152,6 +177,37 @@ void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
             if (d > bestd) { bestd = d; best = kDodecahedronNormals[i]; }
         }
         perturb(h, best * 0.15);
+        return;
+    }
+    case RT_TEX_WRINKLED: {                                 /* TextureMaps.cpp:267-279 */
+        float q[3] = { float(p.x * 50.0), float(p.y * 50.0), float(p.z * 50.0) }, g[3];
+        gradient_fractal_noise(g, q, 3, 6);
+        perturb(h, V3(g[0], g[1], g[2]) * 0.3);
+        return;
+    }
+    case RT_TEX_DENTED: {                                   /* TextureMaps.cpp:307-328 */
+        V3 p2 = p + V3(13.0, 17.0, 31.0);
+        float q[3] = { float(p2.x * 40.0), float(p2.y * 40.0), float(p2.z * 40.0) }, g[3], f;
+        f = gradient_fractal_noise(g, q, 3, 5);
+        if (f < 0.5f) { h.np = h.n; return; }               /* cvPerturbed = cvNormal, nPerturbed untouched */
+        f = 3.0f * f * f;
+        perturb(h, V3(g[0], g[1], g[2]) * (1.0 * f));
+        return;
+    }
+    case RT_TEX_HAMMERED: {                                 /* TextureMaps.cpp:371-387 */
+        float q[3] = { float(p.x * 8.0), float(p.y * 8.0), float(p.z * 8.0) }, g[3];
+        gradient_band_noise(g, q, 3);
+        V3 cv(g[0], g[1], g[2]);
+        gradient_fractal_noise(g, q, 3, 5);
+        V3 cv2(g[0], g[1], g[2]);
+        perturb(h, cv * 0.1 + cv2 * 0.1);
+        return;
+    }
+    case RT_TEX_TECTONIC: {                                 /* TextureMaps.cpp:389-405 */
+        float q[3] = { float(p.x * 3.0), float(p.y * 3.0), float(p.z * 3.0) }, g[3], f;
+        f = gradient_fractal_noise(g, q, 3, 6);
+        if (f < 0.5f) f = 0.0f; else f = -0.4f;
+        perturb(h, V3(g[0], g[1], g[2]) * f);
         return;
     }
     case RT_TEX_WAVY: {                                     /* TextureMaps.cpp:330-336: CoVector3(double) splats the scalar */

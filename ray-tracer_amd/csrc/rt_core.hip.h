@@ -1096,7 +1096,31 @@ __device__ const double kDodeca[20][3] = {
 #undef P2_
 };
 
-RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux)        /* TextureMaps.cpp:209-369 */
+/* GradientFractalNoise, Texture.cpp:243-297: fractal dimension 1, lacunarity 2.1, whole number of levels; omega =
+   powf(2.1f, -1.0f) comes from the host */
+__device__ float gradient_fractal_noise(float *grad, const float *p, int ndim, int levels, float omega)
+{
+    const float lac = 2.1f;
+    float wl = 1.0f, scale = 1.0f, noise = 0.0f, gain = 0.0f, sc[3] = { 0.0f, 0.0f, 0.0f }, bg[3] = { 0.0f, 0.0f, 0.0f };
+    for (int j = 0; j < ndim; j++) { sc[j] = p[j]; grad[j] = 0.0f; }
+    for (int i = 0; i < levels; i++) {
+        float fb = wl * (gradient_band_noise(bg, sc, ndim) - 0.5f);
+        float sign = 1.0f;
+        noise += fb;
+        for (int j = 0; j < ndim; j++) {
+            sc[j] *= lac;
+            grad[j] += bg[j] * scale * wl * sign;
+        }
+        gain += wl;
+        wl *= omega;
+        scale *= lac;
+    }
+    gain = 1.0f / gain;
+    for (int j = 0; j < ndim; j++) grad[j] *= gain;
+    return noise * gain + 0.5f;
+}
+
+RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux, float omega)        /* TextureMaps.cpp:209-369 */
 {
     float q[3], g[3];
     switch (tex) {
@@ -1130,6 +1154,36 @@ RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux)
             if (dd > bestd) { bestd = dd; best = c; }
         }
         perturb(h, best * 0.15);
+        return;
+    }
+    case RT_TEX_WRINKLED:
+        q[0] = (float)(p.x * 50.0); q[1] = (float)(p.y * 50.0); q[2] = (float)(p.z * 50.0);
+        gradient_fractal_noise(g, q, 3, 6, omega);
+        perturb(h, d3(g[0], g[1], g[2]) * 0.3);
+        return;
+    case RT_TEX_DENTED: {
+        D3 p2 = p + d3(13.0, 17.0, 31.0);
+        q[0] = (float)(p2.x * 40.0); q[1] = (float)(p2.y * 40.0); q[2] = (float)(p2.z * 40.0);
+        float f = gradient_fractal_noise(g, q, 3, 5, omega);
+        if (f < 0.5f) { h.np = h.n; return; }               /* cvPerturbed = cvNormal, nPerturbed untouched */
+        f = 3.0f * f * f;
+        perturb(h, d3(g[0], g[1], g[2]) * (1.0 * (double)f));
+        return;
+    }
+    case RT_TEX_HAMMERED: {
+        q[0] = (float)(p.x * 8.0); q[1] = (float)(p.y * 8.0); q[2] = (float)(p.z * 8.0);
+        gradient_band_noise(g, q, 3);
+        D3 cv = d3(g[0], g[1], g[2]);
+        gradient_fractal_noise(g, q, 3, 5, omega);
+        D3 cv2 = d3(g[0], g[1], g[2]);
+        perturb(h, cv * 0.1 + cv2 * 0.1);
+        return;
+    }
+    case RT_TEX_TECTONIC: {
+        q[0] = (float)(p.x * 3.0); q[1] = (float)(p.y * 3.0); q[2] = (float)(p.z * 3.0);
+        float f = gradient_fractal_noise(g, q, 3, 6, omega);
+        if (f < 0.5f) f = 0.0f; else f = -0.4f;
+        perturb(h, d3(g[0], g[1], g[2]) * (double)f);
         return;
     }
     case RT_TEX_WAVY: {
@@ -1184,7 +1238,7 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
         while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == pa) {
             const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
             DRay lr = ray_in_frame(S, wray, tn.tree_affine);
-            apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
+            apply_texture(tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
             it++;
         }
         h.n = covec_mat(h.n, S.affines[pa].minv);
@@ -1193,7 +1247,7 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
     while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == -1) {
         const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
         DRay lr = ray_in_frame(S, wray, tn.tree_affine);
-        apply_texture(tn.tex, ray_at(lr, hr.t), h, aux);
+        apply_texture(tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
         it++;
     }
 }

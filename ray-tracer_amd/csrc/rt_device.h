@@ -186,6 +186,8 @@ typedef struct RtDevScene {
     int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
     int32_t n_bvh_lds, n_chains;        /* BVH nodes staged in LDS; number of chain records */
     int32_t root_cull, root_cull_arg;   /* 0: none; 1: the whole program is union region root_cull_arg; 2: ... is one chain with box root_cull_arg */
+    float   fractal_omega;      /* powf(2.1f, -1.0f) of GradientFractalNoise (Texture.cpp:251), evaluated by the host's libm */
+    int32_t pad1_;
     float   ambient[RT_NSPEC];
     float   spec2rgb[RT_NSPEC][3];
     float   chan[3][RT_NSPEC];

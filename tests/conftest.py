@@ -93,3 +93,19 @@ SCENE_ROW = """(scene
  (pointlight -10 -10 10 (scale (blackbody 6500) 500))
  (camera stereographic 0 0 9 70)
  (sampler fastblue))"""
+
+
+# the fractal-noise bump maps (Wrinkled, Dented, Hammered, Tectonic: GradientFractalNoise, TextureMaps.cpp:267-405) and a
+# hit that queues two call-outs, the inner one Dented (which may overwrite the perturbed normal without flagging it)
+SCENE_FRACTAL = """(scene
+ (model (makeunion
+   (translate -2.2 -1.2 0 (surface shiny wrinkled (material 0.9 auto g_sRed plastic none none (sphere))))
+   (translate 0 -1.2 0 (rotate 0.3 0.1 0 (surface smooth dented (material 0.9 auto g_sGreen plastic none none (cube)))))
+   (translate 2.2 -1.2 0 (surface wet hammered (material 0.9 auto g_sCopper metal none none (scale 1 1.2 1 (sphere)))))
+   (translate -1.2 1.2 0 (surface smooth tectonic (material 0.9 auto g_sYellow plastic none none (cylinder))))
+   (translate 1.2 1.2 0 (surface shiny bumpy (material 0.9 auto g_sCyan plastic dented none (sphere))))
+   (translate 0 3.0 -1 (scale 9 0.2 9 (surface burnished wrinkled (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
+ (camera stereographic 0 0 9 70)
+ (sampler fastblue))"""

@@ -11,7 +11,7 @@ Bars:
 import numpy as np
 import pytest
 
-from conftest import SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
+from conftest import SCENE_FRACTAL, SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +99,7 @@ def test_primary_hit_ids_on_camera_rays_S0(gpu, oracle):
     assert (gc > 0).sum() > 1000
 
 
-@pytest.mark.parametrize("scene", [SCENE_BUMPY], ids=["bumpy"])
+@pytest.mark.parametrize("scene", [SCENE_BUMPY, SCENE_FRACTAL], ids=["bumpy", "fractal"])
 def test_transformed_normals_and_bump_noise(gpu, oracle, scene):
     """a15 + TransformNormals: float lattice noise (integer hash + float splines) is bit exact."""
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
@@ -115,8 +115,8 @@ def test_transformed_normals_and_bump_noise(gpu, oracle, scene):
     assert np.array_equal(gn[notorus], on[notorus])
 
 
-@pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 1e-6), ("S2", 0.0), (SCENE_GLASS, 1e-6), (SCENE_BUMPY, 1e-6), (SCENE_CSG, 1e-6)],
-                         ids=["S0", "S1", "S2", "glass", "bumpy", "csg"])
+@pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 1e-6), ("S2", 0.0), (SCENE_GLASS, 1e-6), (SCENE_BUMPY, 1e-6), (SCENE_CSG, 1e-6), (SCENE_FRACTAL, 1e-6)],
+                         ids=["S0", "S1", "S2", "glass", "bumpy", "csg", "fractal"])
 def test_radiance_matches_oracle(gpu, oracle, scene, tol):
     """a11-a16: RayTracer::VisualRay through the wavefront pipeline (shadow, reflection, refraction queues)."""
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
