@@ -53,7 +53,8 @@ enum { RT_MAT_NOSHADE = 0, RT_MAT_PLASTIC = 1, RT_MAT_METAL = 2, RT_MAT_TRANSPAR
 enum RtTextureId {
     RT_TEX_NONE = 0, RT_TEX_BUMPY = 1, RT_TEX_MICROFACETS = 2, RT_TEX_MICROFACETS2 = 3, RT_TEX_WRINKLED = 4,
     RT_TEX_FACETED20 = 5, RT_TEX_DENTED = 6, RT_TEX_WAVY = 7, RT_TEX_FIBERS = 8, RT_TEX_BLISTERED = 9,
-    RT_TEX_HAMMERED = 10, RT_TEX_TECTONIC = 11, RT_TEX_QUASIMICROFACET = 12, RT_TEX__COUNT
+    RT_TEX_HAMMERED = 10, RT_TEX_TECTONIC = 11, RT_TEX_QUASIMICROFACET = 12, RT_TEX_VORONOIBUMP = 13,
+    RT_TEX_VORONOIANTIBUMP = 14, RT_TEX_VORONOICRINKLED = 15, RT_TEX__COUNT
 };
 /* Propagator function pointers (Solids.h:267); 0 = none. */
 enum RtPropagatorId { RT_PROP_NONE = 0, RT_PROP_COLOREDGLASS = 1, RT_PROP_FOGGY = 2, RT_PROP__COUNT };

@@ -128,6 +128,49 @@ float gradient_fractal_noise(float *grad, const float *p, int ndim, int levels)
     return noise * gain + 0.5f;
 }
 
+
+/* VHash3 + GradientVoronoi, Texture.cpp:318-332, :380-431: nearest feature point among the lattice cells the current
+   best distance can reach; the gradient quirk for nPow > 2 (scaled by fmin only nPow - 2 times) is kept */
+static inline void vhash3(int nx, int ny, int nz, float &x, float &y, float &z)
+{
+    uint32_t n;
+    n = lattice((uint32_t)(nx ^ 1099087573));
+    n = lattice((uint32_t)(ny ^ (int)n ^ 1099087573));
+    n = lattice((uint32_t)(nz ^ (int)n ^ 1099087573));
+    x = nx + float(n) * (1.0f / 4294967296.0f);
+    n = lattice(n ^ 1099087573u);
+    y = ny + float(n) * (1.0f / 4294967296.0f);
+    n = lattice(n ^ 1099087573u);
+    z = nz + float(n) * (1.0f / 4294967296.0f);
+}
+float gradient_voronoi(float *grad, const float *p, int npow)
+{
+    float x = p[0], y = p[1], z = p[2], hx, hy, hz;
+    int nx = int(floorf(x)), ny = int(floorf(y)), nz = int(floorf(z));
+    vhash3(nx, ny, nz, hx, hy, hz);
+    double f = (x - hx) * (x - hx) + (y - hy) * (y - hy) + (z - hz) * (z - hz), fmin = f;
+    grad[0] = hx; grad[1] = hy; grad[2] = hz;
+    f = sqrt(fmin);
+    int i0 = int(floor(x - f)), i1 = int(floor(x + f)), j0 = int(floor(y - f)), j1 = int(floor(y + f)), k0 = int(floor(z - f)), k1 = int(floor(z + f));
+    for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++)
+            for (int k = k0; k <= k1; k++)
+                if (i != nx || j != ny || k != nz) {
+                    vhash3(i, j, k, hx, hy, hz);
+                    f = (x - hx) * (x - hx) + (y - hy) * (y - hy) + (z - hz) * (z - hz);
+                    if (f < fmin) { fmin = f; grad[0] = hx; grad[1] = hy; grad[2] = hz; }
+                }
+    f = fmin;
+    grad[0] = float(npow) * 2.0f * (x - grad[0]);
+    grad[1] = float(npow) * 2.0f * (y - grad[1]);
+    grad[2] = float(npow) * 2.0f * (z - grad[2]);
+    for (int i = 1; i < npow; i++) {
+        f *= fmin;
+        if (i > 1) { grad[0] *= float(fmin); grad[1] *= float(fmin); grad[2] *= float(fmin); }
+    }
+    return float(f);
+}
+
 /* TextureMaps.cpp:189-198 */
 static void perturb(Hit &h, const V3 &d)
 {
@@ -208,6 +251,13 @@ void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
         f = gradient_fractal_noise(g, q, 3, 6);
         if (f < 0.5f) f = 0.0f; else f = -0.4f;
         perturb(h, V3(g[0], g[1], g[2]) * f);
+        return;
+    }
+    case RT_TEX_VORONOIBUMP: case RT_TEX_VORONOIANTIBUMP: case RT_TEX_VORONOICRINKLED: {     /* TextureMaps.cpp:407-441 */
+        float q[3] = { float(p.x * 7.0), float(p.y * 7.0), float(p.z * 7.0) }, g[3];
+        gradient_voronoi(g, q, tex == RT_TEX_VORONOICRINKLED ? 4 : 1);
+        if (tex == RT_TEX_VORONOIBUMP) perturb(h, V3(g[0], g[1], g[2]) * 0.3);
+        else perturb(h, V3(-g[0], -g[1], -g[2]) * 0.3);
         return;
     }
     case RT_TEX_WAVY: {                                     /* TextureMaps.cpp:330-336: CoVector3(double) splats the scalar */

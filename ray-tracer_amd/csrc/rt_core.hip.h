@@ -1096,6 +1096,49 @@ __device__ const double kDodeca[20][3] = {
 #undef P2_
 };
 
+
+/* VHash3 + GradientVoronoi, Texture.cpp:318-332, :380-431: nearest feature point among the lattice cells the current
+   best distance can reach; the gradient quirk for nPow > 2 (scaled by fmin only nPow - 2 times) is kept */
+RT_DEV void vhash3(int nx, int ny, int nz, float &x, float &y, float &z)
+{
+    uint32_t n;
+    n = lattice((uint32_t)(nx ^ 1099087573));
+    n = lattice((uint32_t)(ny ^ (int)n ^ 1099087573));
+    n = lattice((uint32_t)(nz ^ (int)n ^ 1099087573));
+    x = nx + float(n) * (1.0f / 4294967296.0f);
+    n = lattice(n ^ 1099087573u);
+    y = ny + float(n) * (1.0f / 4294967296.0f);
+    n = lattice(n ^ 1099087573u);
+    z = nz + float(n) * (1.0f / 4294967296.0f);
+}
+__device__ float gradient_voronoi(float *grad, const float *p, int npow)
+{
+    float x = p[0], y = p[1], z = p[2], hx, hy, hz;
+    int nx = int(floorf(x)), ny = int(floorf(y)), nz = int(floorf(z));
+    vhash3(nx, ny, nz, hx, hy, hz);
+    double f = (x - hx) * (x - hx) + (y - hy) * (y - hy) + (z - hz) * (z - hz), fmin = f;
+    grad[0] = hx; grad[1] = hy; grad[2] = hz;
+    f = sqrt(fmin);
+    int i0 = int(floor(x - f)), i1 = int(floor(x + f)), j0 = int(floor(y - f)), j1 = int(floor(y + f)), k0 = int(floor(z - f)), k1 = int(floor(z + f));
+    for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++)
+            for (int k = k0; k <= k1; k++)
+                if (i != nx || j != ny || k != nz) {
+                    vhash3(i, j, k, hx, hy, hz);
+                    f = (x - hx) * (x - hx) + (y - hy) * (y - hy) + (z - hz) * (z - hz);
+                    if (f < fmin) { fmin = f; grad[0] = hx; grad[1] = hy; grad[2] = hz; }
+                }
+    f = fmin;
+    grad[0] = float(npow) * 2.0f * (x - grad[0]);
+    grad[1] = float(npow) * 2.0f * (y - grad[1]);
+    grad[2] = float(npow) * 2.0f * (z - grad[2]);
+    for (int i = 1; i < npow; i++) {
+        f *= fmin;
+        if (i > 1) { grad[0] *= float(fmin); grad[1] *= float(fmin); grad[2] *= float(fmin); }
+    }
+    return float(f);
+}
+
 /* GradientFractalNoise, Texture.cpp:243-297: fractal dimension 1, lacunarity 2.1, whole number of levels; omega =
    powf(2.1f, -1.0f) comes from the host */
 __device__ float gradient_fractal_noise(float *grad, const float *p, int ndim, int levels, float omega)
@@ -1186,6 +1229,12 @@ RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux,
         perturb(h, d3(g[0], g[1], g[2]) * (double)f);
         return;
     }
+    case RT_TEX_VORONOIBUMP: case RT_TEX_VORONOIANTIBUMP: case RT_TEX_VORONOICRINKLED:
+        q[0] = (float)(p.x * 7.0); q[1] = (float)(p.y * 7.0); q[2] = (float)(p.z * 7.0);
+        gradient_voronoi(g, q, tex == RT_TEX_VORONOICRINKLED ? 4 : 1);
+        if (tex == RT_TEX_VORONOIBUMP) perturb(h, d3(g[0], g[1], g[2]) * 0.3);
+        else perturb(h, d3(-g[0], -g[1], -g[2]) * 0.3);
+        return;
     case RT_TEX_WAVY: {
         double f = 0.3 * cos(p.z / (2.0 * RT_PI));
         perturb(h, d3(f, f, f));

@@ -474,9 +474,11 @@ Solid *Slaboid(double x, double y, double z, double r)
 }
 
 /* --------------------------------------------------------- texture / propagator identities ---- */
-#define TEXFN(name) void name(const Point3 &, Hit *, RayTracer *) {}
+static volatile int s_texfn_tag;
+#define TEXFN(name) void name(const Point3 &, Hit *, RayTracer *) { s_texfn_tag = __LINE__ * 64 + (int)sizeof(#name); }
 TEXFN(Bumpy) TEXFN(MicroFacets) TEXFN(MicroFacets2) TEXFN(Wrinkled) TEXFN(Faceted20) TEXFN(Dented) TEXFN(Wavy)
 TEXFN(Fibers) TEXFN(Blistered) TEXFN(Hammered) TEXFN(Tectonic) TEXFN(QuasiMicroFacet)
+TEXFN(VoronoiBump) TEXFN(VoronoiAntiBump) TEXFN(VoronoiCrinkled)
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 int rt_texture_id(TextureMap f)
@@ -485,7 +487,8 @@ int rt_texture_id(TextureMap f)
     static const struct { TextureMap f; int id; } map[] = {
         { Bumpy, RT_TEX_BUMPY }, { MicroFacets, RT_TEX_MICROFACETS }, { MicroFacets2, RT_TEX_MICROFACETS2 }, { Wrinkled, RT_TEX_WRINKLED },
         { Faceted20, RT_TEX_FACETED20 }, { Dented, RT_TEX_DENTED }, { Wavy, RT_TEX_WAVY }, { Fibers, RT_TEX_FIBERS },
-        { Blistered, RT_TEX_BLISTERED }, { Hammered, RT_TEX_HAMMERED }, { Tectonic, RT_TEX_TECTONIC }, { QuasiMicroFacet, RT_TEX_QUASIMICROFACET } };
+        { Blistered, RT_TEX_BLISTERED }, { Hammered, RT_TEX_HAMMERED }, { Tectonic, RT_TEX_TECTONIC }, { QuasiMicroFacet, RT_TEX_QUASIMICROFACET },
+        { VoronoiBump, RT_TEX_VORONOIBUMP }, { VoronoiAntiBump, RT_TEX_VORONOIANTIBUMP }, { VoronoiCrinkled, RT_TEX_VORONOICRINKLED } };
     for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) if (map[i].f == f) return map[i].id;
     return -1;
 }

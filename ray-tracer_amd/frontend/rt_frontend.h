@@ -319,6 +319,9 @@ void Blistered(const Point3 &, Hit *, RayTracer *);
 void Hammered(const Point3 &, Hit *, RayTracer *);
 void Tectonic(const Point3 &, Hit *, RayTracer *);
 void QuasiMicroFacet(const Point3 &, Hit *, RayTracer *);
+void VoronoiBump(const Point3 &, Hit *, RayTracer *);
+void VoronoiAntiBump(const Point3 &, Hit *, RayTracer *);
+void VoronoiCrinkled(const Point3 &, Hit *, RayTracer *);
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *);
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *);
 int rt_texture_id(TextureMap f);        /* -1: not a device routine */

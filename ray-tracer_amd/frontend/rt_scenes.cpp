@@ -238,7 +238,8 @@ struct Parser {
         static const struct { const char *n; TextureMap f; } t[] = {
             { "bumpy", Bumpy }, { "microfacets", MicroFacets }, { "microfacets2", MicroFacets2 }, { "wrinkled", Wrinkled }, { "faceted20", Faceted20 },
             { "dented", Dented }, { "wavy", Wavy }, { "fibers", Fibers }, { "blistered", Blistered }, { "hammered", Hammered },
-            { "tectonic", Tectonic }, { "quasimicrofacet", QuasiMicroFacet } };
+            { "tectonic", Tectonic }, { "quasimicrofacet", QuasiMicroFacet }, { "voronoibump", VoronoiBump },
+            { "voronoiantibump", VoronoiAntiBump }, { "voronoicrinkled", VoronoiCrinkled } };
         for (size_t i = 0; i < sizeof t / sizeof t[0]; i++) if (w == t[i].n) return t[i].f;
         fail("unknown texture " + w);
         return 0;

@@ -104,6 +104,8 @@ SCENE_FRACTAL = """(scene
    (translate 2.2 -1.2 0 (surface wet hammered (material 0.9 auto g_sCopper metal none none (scale 1 1.2 1 (sphere)))))
    (translate -1.2 1.2 0 (surface smooth tectonic (material 0.9 auto g_sYellow plastic none none (cylinder))))
    (translate 1.2 1.2 0 (surface shiny bumpy (material 0.9 auto g_sCyan plastic dented none (sphere))))
+   (translate -3.2 1.2 0 (surface shiny voronoibump (material 0.9 auto g_sWhite plastic none none (sphere))))
+   (translate 3.2 1.2 0 (surface shiny voronoicrinkled (material 0.9 auto g_sOrange plastic voronoiantibump none (sphere))))
    (translate 0 3.0 -1 (scale 9 0.2 9 (surface burnished wrinkled (cube))))))
  (ambient (scale (blackbody 6500) 0.02))
  (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
