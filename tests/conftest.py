@@ -111,3 +111,17 @@ SCENE_FRACTAL = """(scene
  (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
  (camera stereographic 0 0 9 70)
  (sampler fastblue))"""
+
+
+# Foggy propagator (TextureMaps.cpp:39-57) around and inside glass, seen through each of the other two cameras
+SCENE_FOG_PERSPECTIVE = """(scene
+ (model (makeunion
+   (translate 0 0 -1 (scale 4 4 4 (material 0.2 1.0 (scale g_sEqualWhite 0.002) transparent none foggy (surface polished none (sphere)))))
+   (translate -1.0 0 -1 (material 0.9 auto g_sRed plastic none none (surface shiny none (sphere))))
+   (translate 1.2 0.3 -0.5 (material 0.9 1.5 (scale g_sEmerald 0.01) transparent none coloredglass (surface polished none (scale 0.7 0.7 0.7 (sphere)))))
+   (translate 0 2.2 -1 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 2000))
+ (camera perspective 0 0 8 50)
+ (sampler fastblue))"""
+SCENE_FOG_ORTHOGRAPHIC = SCENE_FOG_PERSPECTIVE.replace("(camera perspective 0 0 8 50)", "(camera orthographic 0 0 8 4)")

@@ -11,7 +11,7 @@ Bars:
 import numpy as np
 import pytest
 
-from conftest import SCENE_FRACTAL, SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
+from conftest import SCENE_FOG_ORTHOGRAPHIC, SCENE_FOG_PERSPECTIVE, SCENE_FRACTAL, SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
 
 pytestmark = pytest.mark.gpu
 
@@ -306,3 +306,29 @@ def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
         assert np.abs(img - ref).max() <= tol
     band, _ = g.render(w, h, spp, row0=17, row1=41)
     assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
+
+
+@pytest.mark.parametrize("scene", ["S0", "S2", SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC],
+                         ids=["stereographic", "aperture", "perspective", "orthographic"])
+def test_every_camera_emits_the_oracles_rays(gpu, oracle, scene):
+    """a3 Camera::Emit (Cameras.h:8-67) for all four cameras: origins and directions bit exact."""
+    opt, raw, g, o = _pair(gpu, oracle, scene, "")
+    rng = np.random.default_rng(21)
+    v = np.concatenate([rng.uniform(0, 1, (5000, 2)), np.array([[0.5, 0.5], [0.25, 0.5], [0.0, 0.5], [1.0, 1.0]])])   # + TestCamera's inputs (Test.cpp:50-63)
+    aux = rng.uniform(-1, 1, (len(v), 6))
+    go, gd = g.camera(v, aux)
+    oo, od = o.camera(v, aux)
+    assert np.array_equal(go, oo) and np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("scene", [SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC], ids=["perspective", "orthographic"])
+def test_foggy_propagator_and_render(gpu, oracle, scene):
+    """a14 Foggy (TextureMaps.cpp:39-57): transmittance and in-scattered sterisent along every segment of the walk,
+    also on shadow rays; exp() is the device's, so a tolerance instead of equality."""
+    opt, raw, g, o = _pair(gpu, oracle, scene, "fastblue")
+    img, st = g.render(64, 48, 4)
+    rd = gpu.RtRenderDesc(64, 48, 4.0, 0, 0)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(64, 48, 4, rd, ost, threads=4)
+    assert st.samples == n and st.rays() == ost.rays()
+    assert np.abs(img - ref).max() < 2e-5 and ref.mean() > 1e-3
