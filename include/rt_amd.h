@@ -56,6 +56,16 @@ int64_t rt_bmp_size(int width, int height);
 int  rt_bmp_encode(const float *planes, int width, int height, double gamma, unsigned char *file_bytes, int64_t cap);
 int  rt_bmp_encode_device(const float *planes_dev, int width, int height, double gamma, unsigned char *pixels_dev, void *hip_stream);
 
+/* Output stage -- Video (Video.cpp:8-80, YUV4MPEG2 "C444", 30 fps progressive).  rt_y4m_header: the stream header
+   NewVideo writes (Video.cpp:33), returns its length (out == 0: length only); width and height must be multiples of 4
+   (Video.cpp:14).  rt_y4m_encode_frame: Video::WriteFrame (Video.cpp:49-80) for HOST float[3][H][W] planes:
+   "FRAME\n" + the Y, Cb, Cr planes, rt_y4m_frame_size(width, height) bytes; gamma = m_fGamma (Video.h:20, 2.0).
+   rt_y4m_encode_device: planes and the 3*W*H plane bytes both in DEVICE memory, no "FRAME\n", on `hip_stream`. */
+int  rt_y4m_header(int width, int height, char *out, int cap);
+int64_t rt_y4m_frame_size(int width, int height);
+int  rt_y4m_encode_frame(const float *planes, int width, int height, float gamma, unsigned char *frame_bytes, int64_t cap);
+int  rt_y4m_encode_device(const float *planes_dev, int width, int height, float gamma, unsigned char *ycbcr_dev, void *hip_stream);
+
 /* Host-only planning of a row-sharded render (no counterpart in the reference, which renders whole images):
    for output rows [rd->row0, rd->row1) of a FASTBLUE render, the supersample rows [out8[0], out8[1]) the vertical
    filter reads (Sampling.cpp:144-154) and the blue-noise tile rows [out8[2], out8[2] + out8[3]) whose samples can

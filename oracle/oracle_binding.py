@@ -116,6 +116,19 @@ def build_quasi_index(prime, n):
     return out
 
 
+def y4m_encode_frame(planes, gamma=2.0):
+    """Video::WriteFrame restated on the CPU: b"FRAME\\n" + Y, Cb, Cr planes of a [3][H][W] float image."""
+    L = lib()
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    L.orc_y4m_encode_frame.restype = C.c_long
+    L.orc_y4m_encode_frame.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_ubyte), C.c_long]
+    n = L.orc_y4m_encode_frame(_p(planes, C.c_float), w, h, gamma, None, 0)
+    out = np.zeros(n, dtype=np.uint8)
+    assert L.orc_y4m_encode_frame(_p(planes, C.c_float), w, h, gamma, _p(out, C.c_ubyte), n) == n
+    return out
+
+
 def bmp_encode(planes, gamma=-1.0):
     """Image::WriteBMP restated on the CPU: the bytes of the 24-bit BMP file of a [3][H][W] float image."""
     L = lib()

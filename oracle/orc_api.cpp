@@ -738,3 +738,29 @@ extern "C" long orc_bmp_encode(const float *planes, int width, int height, doubl
     }
     return total;
 }
+
+/* Video::WriteFrame (Video.cpp:49-80): "FRAME\n" + Y, Cb, Cr planes (C444).  TEST INFRASTRUCTURE.
+ * pow(float, float) resolves to the float overload under MSVC's <math.h> in C++; powf here. */
+extern "C" long orc_y4m_encode_frame(const float *planes, int width, int height, float gamma, unsigned char *out, long cap)
+{
+    long total = 6 + 3L * width * height;
+    if (!out) return total;
+    if (cap < total) return -1;
+    memcpy(out, "FRAME\n", 6);
+    unsigned char *buf = out + 6;
+    const size_t plane = (size_t)width * height;
+    for (int j = 0; j < height; j++)
+        for (int i = 0; i < width; i++) {
+            size_t o = (size_t)j * width + i;
+            float r = planes[o], g = planes[plane + o], b = planes[2 * plane + o];
+            if (r < 0.0 || r > 1.0 || g < 0.0 || g > 1.0 || b < 0.0 || b > 1.0) orc_clamp_to_gamut(r, g, b);
+            r = powf(r, 1.0f / gamma); g = powf(g, 1.0f / gamma); b = powf(b, 1.0f / gamma);
+            double Y  =  16 +  65.481 * r + 128.553 * g +  24.966 * b;
+            double Cb = 128 -  37.797 * r -  74.203 * g + 112.000 * b;
+            double Cr = 128 + 112.000 * r -  93.786 * g -  18.214 * b;
+            buf[o] = (unsigned char)(int)Y;
+            buf[plane + o] = (unsigned char)(int)Cb;
+            buf[2 * plane + o] = (unsigned char)(int)Cr;
+        }
+    return total;
+}

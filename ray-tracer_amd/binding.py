@@ -106,6 +106,7 @@ def frontend_lib():
         L.rtf_scene_desc.argtypes = [C.c_void_p]
         L.rtf_scene_free.argtypes = [C.c_void_p]
         L.rtf_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(RtStats)]
+        L.rtf_write_video.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_float]
         L.rtf_extent.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
         L.rtf_random_double.argtypes = [C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_double)]
         _frontend = L
@@ -244,3 +245,41 @@ def bmp_encode(planes, gamma=-1.0):
     if rc:
         raise RtError("rt_bmp_encode: %s" % L.rt_last_error().decode())
     return out
+
+
+def y4m_header(width, height):
+    """Video::NewVideo's stream header (rt_y4m_header)."""
+    L = rt_lib()
+    L.rt_y4m_header.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(128)
+    n = L.rt_y4m_header(width, height, buf, 128)
+    if n < 0:
+        raise RtError("rt_y4m_header: %s" % L.rt_last_error().decode())
+    return buf.raw[:n]
+
+
+def y4m_encode_frame(planes, gamma=2.0):
+    """Video::WriteFrame on the GPU (rt_y4m_encode_frame): b"FRAME\\n" + Y, Cb, Cr planes of a [3][H][W] float image."""
+    L = rt_lib()
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    L.rt_y4m_frame_size.restype = C.c_int64
+    L.rt_y4m_frame_size.argtypes = [C.c_int, C.c_int]
+    L.rt_y4m_encode_frame.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_ubyte), C.c_int64]
+    n = L.rt_y4m_frame_size(w, h)
+    out = np.zeros(n, dtype=np.uint8)
+    rc = L.rt_y4m_encode_frame(planes.ctypes.data_as(C.POINTER(C.c_float)), w, h, float(gamma), out.ctypes.data_as(C.POINTER(C.c_ubyte)), n)
+    if rc:
+        raise RtError("rt_y4m_encode_frame: %s" % L.rt_last_error().decode())
+    return out
+
+
+def write_video(path, frames, gamma=2.0):
+    """The front end's Video class (NewVideo, WriteFrame per image, Close) over a list of [3][H][W] float images."""
+    L = frontend_lib()
+    fr = np.ascontiguousarray(np.stack(frames), dtype=np.float32)
+    n, _, h, w = fr.shape
+    rc = L.rtf_write_video(path.encode(), _p(fr, C.c_float), n, w, h, float(gamma))
+    if rc < 0:
+        raise RtError(L.rtf_last_error().decode())
+    return rc

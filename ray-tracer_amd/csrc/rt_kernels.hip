@@ -946,4 +946,42 @@ __global__ void __launch_bounds__(256) k_bmp_encode(const float *planes, int wid
     p[2] = (unsigned char)gamma_encode(A, red);
 }
 
+/* ------------------------------------------------------------------ output stage: Video::WriteFrame, Video.cpp:49-80
+ * One thread per pixel: ClampToGamut when a channel leaves [0,1], pow(c, 1.0f/m_fGamma) in float, the BT.601
+ * studio-range matrix in double, int() truncation, three planes Y, Cb, Cr of W*H bytes (C444).  The float pow is
+ * the only libm call: here it is the double pow rounded to float (the correctly rounded value in all but
+ * astronomically rare cases); a CPU powf may differ from that by one ulp, which moves a byte by one code at most. */
+__global__ void __launch_bounds__(256) k_y4m_encode(const float *planes, int width, int height, float inv_gamma, unsigned char *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= width) return;
+    size_t plane = (size_t)width * height, o = (size_t)j * width + i;
+    float red = planes[o], grn = planes[plane + o], blu = planes[2 * plane + o];
+    if (red < 0.0 || red > 1.0 || grn < 0.0 || grn > 1.0 || blu < 0.0 || blu > 1.0) {
+        float fLum = 0.2126f * red + 0.7152f * grn + 0.0722f * blu, t;      /* Luminance(), Image.h:110-115 */
+        if (fLum < 0.0) red = grn = blu = 0.0f;
+        else if (fLum > 1.0) red = grn = blu = 1.0f;
+        else {
+            t = 1.0;
+            if (red < 0.0 && -fLum > (red - fLum) * t) t = -fLum / (red - fLum);
+            if (red > 1.0 && 1.0 - fLum < (red - fLum) * t) t = (1.0f - fLum) / (red - fLum);
+            if (grn < 0.0 && -fLum > (grn - fLum) * t) t = -fLum / (grn - fLum);
+            if (grn > 1.0 && 1.0 - fLum < (grn - fLum) * t) t = (1.0f - fLum) / (grn - fLum);
+            if (blu < 0.0 && -fLum > (blu - fLum) * t) t = -fLum / (blu - fLum);
+            if (blu > 1.0 && 1.0 - fLum < (blu - fLum) * t) t = (1.0f - fLum) / (blu - fLum);
+            float r = fLum + t * (red - fLum), g = fLum + t * (grn - fLum), b = fLum + t * (blu - fLum);
+            red = r; grn = g; blu = b;
+        }
+    }
+    red = (float)pow((double)red, (double)inv_gamma);
+    grn = (float)pow((double)grn, (double)inv_gamma);
+    blu = (float)pow((double)blu, (double)inv_gamma);
+    double Y  =  16 +  65.481 * red + 128.553 * grn +  24.966 * blu;
+    double Cb = 128 -  37.797 * red -  74.203 * grn + 112.000 * blu;
+    double Cr = 128 + 112.000 * red -  93.786 * grn -  18.214 * blu;
+    out[o] = (unsigned char)(int)Y;
+    out[plane + o] = (unsigned char)(int)Cb;
+    out[2 * plane + o] = (unsigned char)(int)Cr;
+}
+
 #include "rt_api.inc"

@@ -711,6 +711,37 @@ int Image::WriteBMP(const char *szFileName, double fGamma)
     return w == (size_t)n ? 1 : 0;
 }
 
+int Video::NewVideo(const char *szFileName, Image &im)
+{
+    char h[128];
+    if (im.m_nChannels != 3) return 0;
+    int n = rt_y4m_header(im.m_nWidth, im.m_nHeight, h, (int)sizeof h);
+    if (n < 0) { snprintf(s_err, sizeof s_err, "rt_y4m_header: %s", rt_last_error()); return 0; }
+    hFile = fopen(szFileName, "wb");
+    if (!hFile) return 0;
+    m_nHeight = im.m_nHeight; m_nWidth = im.m_nWidth;
+    return fwrite(h, 1, (size_t)n, hFile) == (size_t)n ? 1 : 0;
+}
+
+int Video::WriteFrame(Image &im)
+{
+    if (!hFile || im.m_nChannels != 3 || im.m_nWidth != m_nWidth || im.m_nHeight != m_nHeight) return 0;
+    int64_t n = rt_y4m_frame_size(m_nWidth, m_nHeight);
+    std::vector<unsigned char> bytes((size_t)n);
+    if (rt_y4m_encode_frame(im.m_pfImage, m_nWidth, m_nHeight, m_fGamma, &bytes[0], n)) {
+        snprintf(s_err, sizeof s_err, "rt_y4m_encode_frame: %s", rt_last_error());
+        return 0;
+    }
+    return fwrite(&bytes[0], 1, (size_t)n, hFile) == (size_t)n ? 1 : 0;
+}
+
+int Video::Close()
+{
+    if (hFile) fclose(hFile);
+    hFile = 0; m_nHeight = m_nWidth = 0;
+    return 1;
+}
+
 int RayTracer::Render(Image &im, double spp)
 {
     RtSceneBlob blob;

@@ -188,6 +188,18 @@ private:
     Image &operator=(const Image &);
 };
 
+/* ----------------------------------------------------------------------------- Video (Video.h) ---- */
+struct Video {                                  /* YUV4MPEG2 writer, Video.cpp:8-80; frames encoded on the GPU (rt_y4m_encode_frame) */
+    FILE *hFile;
+    int   m_nHeight, m_nWidth;
+    float m_fGamma;
+    Video() : hFile(0), m_nHeight(0), m_nWidth(0), m_fGamma(2.0) {}
+    int   NewVideo(const char *szFileName, Image &im);
+    int   WriteFrame(Image &im);
+    int   Close();
+    float SetGamma(float fGamma) { return m_fGamma = fGamma; }
+};
+
 /* -------------------------------------------------------- rays, extents (RayTracer2020.h) ---- */
 struct Ray {
     Point3 pOrg; Vector3 vDir; double tMin; int bPrimary;

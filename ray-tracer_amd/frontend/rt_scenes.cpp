@@ -452,3 +452,20 @@ extern "C" void rtf_random_double(unsigned x, unsigned c, int n, double *out)
     ML_InitializeRandom(x, c);
     for (int i = 0; i < n; i++) out[i] = RandomDouble();
 }
+
+/* Video::NewVideo / WriteFrame / Close over nframes images float[nframes][3][H][W]; returns frames written */
+extern "C" int rtf_write_video(const char *path, const float *frames, int nframes, int width, int height, float gamma)
+{
+    Image im;
+    Video vd;
+    im.NewImage(width, height, 3);
+    vd.SetGamma(gamma);
+    if (!vd.NewVideo(path, im)) { snprintf(s_scene_err, sizeof s_scene_err, "NewVideo: %s", rt_frontend_last_error()); return -1; }
+    int n = 0;
+    for (; n < nframes; n++) {
+        memcpy(im.m_pfImage, frames + (size_t)n * 3 * width * height, sizeof(float) * 3 * (size_t)width * height);
+        if (!vd.WriteFrame(im)) { snprintf(s_scene_err, sizeof s_scene_err, "WriteFrame: %s", rt_frontend_last_error()); break; }
+    }
+    vd.Close();
+    return n;
+}

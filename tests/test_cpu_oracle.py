@@ -182,6 +182,30 @@ def test_bmp_restatement_layout_and_gamma(oracle):
     assert oracle.bmp_encode(grey)[54] in (127, 128)
 
 
+def test_y4m_restatement(rt, oracle):
+    """Video::WriteFrame restated (Video.cpp:49-80): "FRAME\\n", then the Y, Cb, Cr planes in image row order; black is
+    (16, 128, 128), white (235, 128, 128), primaries at the BT.601 studio-range corners; gamma 2 is a square root.  The
+    header (host-only entry point) is the text NewVideo writes and sizes that are not multiples of 4 are refused."""
+    img = np.zeros((3, 4, 4), dtype=np.float32)
+    img[:, 0, 1] = 1.0                              # white
+    img[0, 0, 2] = 1.0                              # red
+    img[1, 0, 3] = 1.0                              # green
+    img[2, 1, 0] = 1.0                              # blue
+    img[:, 1, 1] = 0.25                             # sqrt -> 0.5 grey
+    f = oracle.y4m_encode_frame(img)
+    assert len(f) == 6 + 48 and f[:6].tobytes() == b"FRAME\n"
+    Y, Cb, Cr = (f[6 + 16 * k:6 + 16 * (k + 1)].reshape(4, 4) for k in range(3))
+    assert (Y[0, 0], Cb[0, 0], Cr[0, 0]) == (16, 128, 128)
+    assert (Y[0, 1], Cb[0, 1], Cr[0, 1]) == (235, 128, 128)
+    assert (Y[0, 2], Cb[0, 2], Cr[0, 2]) == (81, 90, 240)
+    assert (Y[0, 3], Cb[0, 3], Cr[0, 3]) == (144, 53, 34)
+    assert (Y[1, 0], Cb[1, 0], Cr[1, 0]) == (40, 240, 109)
+    assert (Y[1, 1], Cb[1, 1], Cr[1, 1]) == (int(16 + 219 * 0.5), 128, 128)
+    assert rt.y4m_header(1280, 720) == b"YUV4MPEG2 W1280 H720 F30:1 Ip A1:1 C444\n"
+    with pytest.raises(rt.RtError):
+        rt.y4m_header(1281, 720)
+
+
 def test_random_skip_equals_stepping(rt):
     """rt_random_skip (MWC as multiplication by a modulo a 2^32 - 1) lands where RandomUnsigned would after n draws."""
     import ctypes as C

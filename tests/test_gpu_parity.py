@@ -285,6 +285,30 @@ def test_bmp_output_stage_is_byte_exact(gpu, oracle):
         assert a[:2].tobytes() == b"BM" and np.array_equal(a, b), gamma
 
 
+def test_y4m_output_stage(gpu, oracle, tmp_path):
+    """8f-2 Video::WriteFrame on the GPU against the CPU restatement.  Its one libm call is a float pow: with the
+    default gamma 2 (exponent 0.5, where both sides return the rounded square root) the frame is byte exact; for
+    other gammas a byte may differ by one code where the two pow results differ in the last bit (bounded here at
+    1 code on < 0.1 % of the bytes).  Then the front end's Video class writes header + frames that parse back."""
+    fs = gpu.FrontScene("S1", "fastblue", optimize=True)
+    img, _ = gpu.GpuScene(fs.desc).render(96, 64, 4)
+    a, b = gpu.y4m_encode_frame(img), oracle.y4m_encode_frame(img)
+    assert a[:6].tobytes() == b"FRAME\n" and np.array_equal(a, b)
+    rng = np.random.default_rng(12)
+    wild = rng.normal(0.5, 0.6, (3, 36, 52)).astype(np.float32)
+    wild[:, 0, :6] = np.array([[-1, 0, 1, 2, 1e-9, 0.5]] * 3, dtype=np.float32)
+    for gamma in (2.0, 2.2, 1.0):
+        a, b = gpu.y4m_encode_frame(wild, gamma).astype(int), oracle.y4m_encode_frame(wild, gamma).astype(int)
+        d = np.abs(a - b)
+        assert d.max() <= (0 if gamma in (2.0, 1.0) else 1) and (d > 0).mean() < 1e-3, (gamma, d.max(), (d > 0).mean())
+    path = str(tmp_path / "v.y4m")
+    assert gpu.write_video(path, [img, img[:, ::-1].copy()]) == 2
+    data = open(path, "rb").read()
+    hdr = gpu.y4m_header(96, 64)
+    assert data.startswith(hdr) and len(data) == len(hdr) + 2 * (6 + 3 * 96 * 64)
+    assert data[len(hdr):len(hdr) + 6 + 3 * 96 * 64] == oracle.y4m_encode_frame(img).tobytes()
+
+
 @pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 2e-5)])
 def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
     """a1 JitterSamplingTile (Sampling.cpp:394-419): sample positions from the MWC stream (skip-ahead on the host,
