@@ -70,6 +70,13 @@ class OracleScene:
         tot = self.L.orc_jitter_samples(self.h, width, height, float(spp), first, n, _p(out, C.c_double))
         return out, tot
 
+    def bluenoise_samples(self, width, height, spp, first, n):
+        out8 = np.zeros((n, 8)); xy = np.zeros((n, 2))
+        self.L.orc_bluenoise_samples.restype = C.c_long
+        self.L.orc_bluenoise_samples.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_long, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        tot = self.L.orc_bluenoise_samples(self.h, width, height, float(spp), first, n, _p(out8, C.c_double), _p(xy, C.c_double))
+        return out8, xy, tot
+
     def camera(self, v2, aux=None):
         v2 = np.ascontiguousarray(v2, dtype=np.float64); n = len(v2)
         org = np.zeros((n, 3)); dr = np.zeros((n, 3))

@@ -71,6 +71,9 @@ extern "C" int orc_load_tables(const char *path)
     if (!find_table(blob, "g_rgvBlueNoise", dt, cnt, off) || dt != 1 || cnt != 2 * RT_BLUE_N) return -5;
     g_t.blue.resize(cnt);
     memcpy(&g_t.blue[0], &blob[off], sizeof(double) * cnt);
+    if (!find_table(blob, "DiskSamples128", dt, cnt, off) || dt != 1 || cnt != 256) return -6;
+    g_t.disk128.resize(cnt);
+    memcpy(&g_t.disk128[0], &blob[off], sizeof(double) * cnt);
     g_t.loaded = true;
     return 0;
 }
@@ -475,6 +478,107 @@ static void normalize_image(Img &im, const Img &wt)
         }
 }
 
+/* float Kaiser4Filter of the splats, Image.cpp:886-918 (the resampler has its own double one, Sampling.cpp:40-65) */
+static float kaiser4_filter_f(float x)
+{
+    static double gs_fI0Alpha = 1.0 / 11.3019219521363, gs_fAlphaSquared = 4.0 * 4.0;
+    float x1, x2, xTerm, fN, fSinc, fKaiser;
+    x1 = x * 1.0f / 4.0f;
+    x2 = x1 * x1;
+    if (x2 > 1.0) return 0.0;
+    x2 = 0.25f * float(gs_fAlphaSquared) * (1.0f - x2);
+    fKaiser = 1.0f + x2;
+    fN = 2.0f;
+    xTerm = x2;
+    while (xTerm > 1.0e-4) {
+        xTerm *= x2 / (fN * fN);
+        fN += 1.0;
+        fKaiser += xTerm;
+        xTerm *= x2 / (fN * fN);
+        fN += 1.0;
+        fKaiser += xTerm;
+    }
+    x1 = 3.1415926535897932384626433832795028842f * x;
+    x2 = x1 * x1;
+    if (x2 < 0.0001f) fSinc = 1.0f + x2 * (-1.0f / 6.0f + x2 * 1.0f / 120.0f);
+    else fSinc = sinf(x1) / x1;
+    return fSinc * fKaiser * float(gs_fI0Alpha);
+}
+static inline int wrap_mirror(int i, int n)             /* ML_Wrap with WRAP_MIRROR, Image.cpp:59-83 */
+{
+    i = i % (2 * n);
+    if (i < 0) i += 2 * n;
+    if (i >= n) i = 2 * n - i - 1;
+    return i;
+}
+/* Image::SplatRGB(rgb, xSample, ySample, pimWeight, fScale = 1) (Image.cpp:1203-1236) into images created with
+   NewImage's default WRAP_MIRROR (Image.h:157): out-of-range indices fold back into the image. */
+static void kaiser_splat(Img &im, Img &wt, const Rgb &rgb, double xSample, double ySample)
+{
+    double x, y, xLow, xHigh, yLow, yHigh, fWeightX, fWeight, fRecipScale, fHalfWidth, fScale = 1.0;
+    int i, j, iLow, jLow;
+    float rgf[512];
+    fHalfWidth = 4.0f;
+    xLow = xSample - fHalfWidth * fScale;
+    xHigh = xSample + fHalfWidth * fScale;
+    iLow = lowest_index(xLow);
+    yLow = ySample - fHalfWidth * fScale;
+    yHigh = ySample + fHalfWidth * fScale;
+    jLow = lowest_index(yLow);
+    fRecipScale = 1.0 / fScale;
+    for (j = jLow, y = double(jLow) + 0.5; y <= yHigh; j++, y += 1.0) rgf[j - jLow] = kaiser4_filter_f(float((y - ySample) * fRecipScale));
+    rgf[j - jLow] = 0.0;
+    for (i = iLow, x = double(iLow) + 0.5; x <= xHigh; i++, x += 1.0) {
+        fWeightX = kaiser4_filter_f(float((x - xSample) * fRecipScale));
+        for (j = jLow, y = double(jLow) + 0.5; y <= yHigh; j++, y += 1.0) {
+            fWeight = fWeightX * rgf[j - jLow];
+            int ii = wrap_mirror(i, im.w), jj = wrap_mirror(j, im.h);
+            im.at(ii, jj, 0) += float(rgb.r * fWeight);         /* rgb*fWeight: DisplayRGB(red*f, ...), Image.h:69 */
+            im.at(ii, jj, 1) += float(rgb.g * fWeight);
+            im.at(ii, jj, 2) += float(rgb.b * fWeight);
+            wt.at(ii, jj, 0) += float(fWeight);
+        }
+    }
+}
+
+extern "C" void orc_build_quasi_index(int *out, int prime, int n);
+
+/* BlueNoiseSamplingTile (Sampling.cpp:427-466): tile positions by accumulation, sample positions and the six
+   auxiliary dimensions (DiskSamples128 through rgnQuasiIndex2/3/5) in loop order */
+struct BlueNoisePlan {
+    double fSqrt, fSize, ax, ay;
+    std::vector<double> txs, tys;
+    int q[3][128];
+    BlueNoisePlan(int W, int H, double spp)
+    {
+        fSqrt = double(RT_BLUE_NSQRT) / sqrt(spp);
+        if (W > H) { fSize = W; ax = 0.0; ay = 0.5 * (W - H); } else { fSize = H; ax = 0.5 * (H - W); ay = 0.0; }
+        for (double x = 0.0; x < W; x += fSqrt) txs.push_back(x);
+        for (double y = 0.0; y < H; y += fSqrt) tys.push_back(y);
+        orc_build_quasi_index(q[0], 2, 128); orc_build_quasi_index(q[1], 3, 128); orc_build_quasi_index(q[2], 5, 128);
+    }
+    void sample(long tile, int i, double &vx, double &vy, double *aux) const
+    {
+        double tx = txs[tile / (long)tys.size()], ty = tys[tile % (long)tys.size()];
+        vx = g_t.blue[2 * i] * fSqrt + tx; vy = g_t.blue[2 * i + 1] * fSqrt + ty;
+        for (int k = 0; k < 3; k++) { aux[2 * k] = g_t.disk128[2 * q[k][i & 127]]; aux[2 * k + 1] = g_t.disk128[2 * q[k][i & 127] + 1]; }
+    }
+};
+
+extern "C" long orc_bluenoise_samples(void *h, int width, int height, double spp, long first, long n, double *out8, double *out_xy)
+{
+    (void)h;
+    BlueNoisePlan P(width, height, spp);
+    long total = (long)P.txs.size() * (long)P.tys.size() * RT_BLUE_N;
+    for (long idx = first; idx < first + n && idx < total && out8; idx++) {
+        double vx, vy, *o = out8 + 8 * (idx - first);
+        P.sample(idx / RT_BLUE_N, (int)(idx % RT_BLUE_N), vx, vy, o + 2);
+        o[0] = (vx + P.ax) / P.fSize; o[1] = (vy + P.ay) / P.fSize;
+        if (out_xy) { out_xy[2 * (idx - first)] = vx; out_xy[2 * (idx - first) + 1] = vy; }
+    }
+    return total;
+}
+
 static Rgb sample_rgb(Scene &s, double vx, double vy, Ctx &cx)      /* CastFunction, RayTracer2020.cpp:20-31 */
 {
     Ray r = camera_emit(s.cam, vx, vy, cx);
@@ -606,6 +710,35 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
         if (sample_rgb_out) memcpy(sample_rgb_out, &rgb[0], sizeof(Rgb) * rgb.size());
         Img im;
         image_resample(im, W, H, im2);
+        memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
+    } else if (s->sampler_type == RT_SAMPLER_BLUENOISE) {
+        /* BlueNoiseSamplingTile::Render, Sampling.cpp:427-466: radiance evaluation spread over threads, splats serial in
+           the reference's order */
+        BlueNoisePlan P(W, H, rd->spp);
+        long ntile = (long)P.txs.size() * (long)P.tys.size();
+        std::vector<Rgb> rgb((size_t)ntile * RT_BLUE_N);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(+:np,nsh,nsec)
+        for (long tile = 0; tile < ntile; tile++) {
+            Ctx cx;
+            for (int i = 0; i < RT_BLUE_N; i++) {
+                double vx, vy;
+                P.sample(tile, i, vx, vy, cx.aux);
+                rgb[(size_t)tile * RT_BLUE_N + i] = sample_rgb(*s, (vx + P.ax) / P.fSize, (vy + P.ay) / P.fSize, cx);
+            }
+            np += cx.n_primary; nsh += cx.n_shadow; nsec += cx.n_secondary;
+        }
+        Img im, wt;
+        im.alloc(W, H, 3);
+        wt.alloc(W, H, 1);
+        for (long tile = 0; tile < ntile; tile++)
+            for (int i = 0; i < RT_BLUE_N; i++) {
+                double vx, vy, aux[6];
+                P.sample(tile, i, vx, vy, aux);
+                kaiser_splat(im, wt, rgb[(size_t)tile * RT_BLUE_N + i], vx, vy);
+            }
+        ns = ntile * RT_BLUE_N;
+        if (sample_rgb_out) memcpy(sample_rgb_out, &rgb[0], sizeof(Rgb) * rgb.size());
+        normalize_image(im, wt);
         memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
     } else {
         double spp = rd->spp;

@@ -35,6 +35,7 @@ struct Tables {
     float spec2rgb[NSPEC][3];
     Spec  chan[3];                      /* g_sRedChannel, g_sGrnChannel, g_sBluChannel */
     std::vector<double> blue;           /* g_rgvBlueNoise, 1600 x 2 */
+    std::vector<double> disk128;        /* DiskSamples128, 128 x 2 (LowDiscrepancy.cpp:129) */
     Tables() : loaded(false) {}
 };
 extern Tables g_t;

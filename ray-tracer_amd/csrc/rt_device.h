@@ -182,6 +182,8 @@ typedef struct RtDevScene {
     const int32_t       *region_lca;
     const double        *blue;          /* g_rgvBlueNoise: 1600 x 2 */
     const int32_t       *qi2, *qi3;     /* g_BlueNoiseQuasiIndex2/3 */
+    const double        *disk128;       /* DiskSamples128: 128 x 2 (LowDiscrepancy.cpp:129) */
+    const int32_t       *q128;          /* rgnQuasiIndex2, 3, 5: 3 x 128 (LowDiscrepancy.cpp:262-333) */
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
     int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
     int32_t n_bvh_lds, n_chains;        /* BVH nodes staged in LDS; number of chain records */

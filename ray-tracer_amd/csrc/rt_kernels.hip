@@ -77,6 +77,20 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
         for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
         return;
     }
+    if (g.sampler == RT_SAMPLER_BLUENOISE) {            /* BlueNoiseSamplingTile::Render, Sampling.cpp:448-458 */
+        const uint32_t tile = (uint32_t)(s / RT_BLUE_N);
+        const int i = (int)(s - (int64_t)tile * RT_BLUE_N);
+        const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+        const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
+        const double vx = S.blue[2 * i] * g.bn_sqrt + g.bn_tx[tx], vy = S.blue[2 * i + 1] * g.bn_sqrt + g.bn_ty[ty];
+        pos2[0] = vx; pos2[1] = vy;
+        v2[0] = (vx + g.adjust_x) / g.size; v2[1] = (vy + g.adjust_y) / g.size;
+        const int q2 = S.q128[i & 127], q3 = S.q128[128 + (i & 127)], q5 = S.q128[256 + (i & 127)];
+        aux[0] = S.disk128[2 * q2]; aux[1] = S.disk128[2 * q2 + 1];
+        aux[2] = S.disk128[2 * q3]; aux[3] = S.disk128[2 * q3 + 1];
+        aux[4] = S.disk128[2 * q5]; aux[5] = S.disk128[2 * q5 + 1];
+        return;
+    }
     /* FastBlueSamplingTile::Render, Sampling.cpp:498-517: tile x outer, tile y inner, i innermost */
     const uint32_t tile = (uint32_t)(s / RT_BLUE_N);      /* < 2^31 tiles (checked by the host) */
     int i = (int)(s - (int64_t)tile * RT_BLUE_N);
@@ -781,6 +795,108 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
     size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
     im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b;
     wt2[o] = w;
+}
+
+/* ------------------------------------------------------------------ BlueNoiseSamplingTile reconstruction
+ * Image::SplatRGB (Image.cpp:1203-1236) spreads every sample over the <= 9 x 9 output pixels under a separable
+ * Kaiser-windowed sinc (float Kaiser4Filter, Image.cpp:890-918), into an image whose indices wrap by mirroring
+ * (NewImage's default, Image.h:157; ML_Wrap, Image.cpp:59-83), then Normalize (Image.cpp:1238-1260).  As with the
+ * bilinear splat, every output pixel GATHERS its contributions in the reference's order (tile x outer, tile y inner,
+ * sample index, x index, y index) so the float sums come out the same without atomics: a wave owns 8 x 8 pixels,
+ * walks the tiles within reach and tests all 1600 samples of each (their positions are wave-uniform). */
+RT_DEV float kaiser4_filter_f(float x)
+{
+    float x1, x2, xTerm, fN, fSinc, fKaiser;
+    x1 = x * 1.0f / 4.0f;
+    x2 = x1 * x1;
+    if (x2 > 1.0) return 0.0;
+    x2 = 0.25f * 16.0f * (1.0f - x2);
+    fKaiser = 1.0f + x2;
+    fN = 2.0f;
+    xTerm = x2;
+    while (xTerm > 1.0e-4) {
+        xTerm *= x2 / (fN * fN);
+        fN += 1.0;
+        fKaiser += xTerm;
+        xTerm *= x2 / (fN * fN);
+        fN += 1.0;
+        fKaiser += xTerm;
+    }
+    x1 = 3.1415926535897932384626433832795028842f * x;
+    x2 = x1 * x1;
+    if (x2 < 0.0001f) fSinc = 1.0f + x2 * (-1.0f / 6.0f + x2 * 1.0f / 120.0f);
+    else fSinc = (float)sin((double)x1) / x1;       /* sinf: the double sine rounded to float */
+    return fSinc * fKaiser * (float)(1.0 / 11.3019219521363);
+}
+RT_DEV int mirror_index(int i, int n)                   /* ML_Wrap, WRAP_MIRROR */
+{
+    i = i % (2 * n);
+    if (i < 0) i += 2 * n;
+    if (i >= n) i = 2 * n - i - 1;
+    return i;
+}
+/* indices q of [lo, hi] that land on pixel p of an axis of n pixels, ascending; most samples: none or one */
+RT_DEV int axis_matches(int lo, int hi, int p, int n, int *q /*[9]*/)
+{
+    if (lo >= 0 && hi < n) { if (p < lo || p > hi) return 0; q[0] = p; return 1; }
+    int c = 0;
+    for (int k = lo; k <= hi && c < 9; k++) if (mirror_index(k, n) == p) q[c++] = k;
+    return c;
+}
+__global__ void __launch_bounds__(256) k_kaiser_gather(const RtDevScene Sv, RtSampleGrid g, const float *sample_rgb, int row0, int row1, float *planes)
+{
+    __shared__ double s_b[2 * RT_BLUE_N];
+    const RtDevScene &S = Sv;
+    for (int k = threadIdx.x; k < 2 * RT_BLUE_N; k += blockDim.x) s_b[k] = S.blue[k] * g.bn_sqrt;      /* g_rgvBlueNoise[i]*fSqrt */
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7), py = row0 + blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
+    const int W = g.width, H = g.height;
+    if (px >= W || py >= row1) return;
+    /* tiles whose samples can reach this pixel, directly or through the mirrored border (generous: every sample is tested) */
+    const double xt = g.bn_tx[g.tiles_x - 1] + g.bn_sqrt, yt = g.bn_ty[g.tiles_y - 1] + g.bn_sqrt;
+    double xlo = (double)px - 5.0, xhi = (double)px + 6.0, ylo = (double)py - 5.0, yhi = (double)py + 6.0;
+    if (2.0 * W - 1.0 - px - 5.0 < xt) xhi = 2.0 * W - px + 5.0;
+    if (2.0 * H - 1.0 - py - 5.0 < yt) yhi = 2.0 * H - py + 5.0;
+    int tx0 = (int)floor(xlo / g.bn_sqrt) - 2, tx1 = (int)floor(xhi / g.bn_sqrt) + 1, ty0 = (int)floor(ylo / g.bn_sqrt) - 2, ty1 = (int)floor(yhi / g.bn_sqrt) + 1;
+    if (W < 16) { tx0 = 0; tx1 = g.tiles_x - 1; }
+    if (H < 16) { ty0 = 0; ty1 = g.tiles_y - 1; }
+    if (tx0 < 0) tx0 = 0;
+    if (tx1 > g.tiles_x - 1) tx1 = g.tiles_x - 1;
+    if (ty0 < g.tile_y0) ty0 = g.tile_y0;
+    if (ty1 > g.tile_y0 + g.tiles_y_local - 1) ty1 = g.tile_y0 + g.tiles_y_local - 1;
+    float r = 0.0f, gg = 0.0f, b = 0.0f, w = 0.0f;
+    for (int tx = tx0; tx <= tx1; tx++) {
+        const double vtx = g.bn_tx[tx];
+        for (int ty = ty0; ty <= ty1; ty++) {
+            const double vty = g.bn_ty[ty];
+            const float *c0 = sample_rgb + 3 * (((int64_t)tx * g.tiles_y_local + (ty - g.tile_y0)) * RT_BLUE_N);
+            for (int i = 0; i < RT_BLUE_N; i++) {
+                const double vx = s_b[2 * i] + vtx, vy = s_b[2 * i + 1] + vty;
+                const int iLow = (int)floor((vx - 4.0) + 0.5), iHigh = (int)floor((vx + 4.0) - 0.5);
+                int qx[9], qy[9];
+                const int nx = axis_matches(iLow, iHigh, px, W, qx);
+                if (nx == 0) continue;
+                const int jLow = (int)floor((vy - 4.0) + 0.5), jHigh = (int)floor((vy + 4.0) - 0.5);
+                const int ny = axis_matches(jLow, jHigh, py, H, qy);
+                if (ny == 0) continue;
+                const float cr = c0[3 * i], cg = c0[3 * i + 1], cb = c0[3 * i + 2];
+                for (int a = 0; a < nx; a++) {
+                    const double fWeightX = kaiser4_filter_f((float)((((double)qx[a] + 0.5) - vx) * 1.0));
+                    for (int e = 0; e < ny; e++) {
+                        const double fWeight = fWeightX * kaiser4_filter_f((float)((((double)qy[e] + 0.5) - vy) * 1.0));
+                        r += (float)((double)cr * fWeight);
+                        gg += (float)((double)cg * fWeight);
+                        b += (float)((double)cb * fWeight);
+                        w += (float)fWeight;
+                    }
+                }
+            }
+        }
+    }
+    if (w) { r /= w; gg /= w; b /= w; }                 /* Image::Normalize */
+    const size_t o = (size_t)py * W + px, plane = (size_t)W * H;
+    planes[o] = r; planes[plane + o] = gg; planes[2 * plane + o] = b;
 }
 
 /* Resample (Sampling.cpp:131-184), WRAP_CLAMP.  src: [planes][src_rows][src_n] -> dst laid out [planes][src_rows][dst_n] */

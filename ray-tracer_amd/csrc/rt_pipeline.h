@@ -52,6 +52,9 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     int     jit_segs;                   /* JITTER: 64-pixel segments per supersample row */
     const uint32_t *jit_states;         /* JITTER: MWC state (x, c) at the start of every segment of the traced rows */
     int     pad_;
+    /* BLUENOISE (Sampling.cpp:427-466): tiles of bn_sqrt output pixels at the accumulated positions bn_tx[tiles_x], bn_ty[tiles_y] */
+    double  bn_sqrt;
+    const double *bn_tx, *bn_ty;
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;

@@ -525,6 +525,8 @@ struct SamplingTile {
 struct TestSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_TEST; } };
 /* JitterSamplingTile (Sampling.cpp:388-419): one sample per supersample pixel, jittered by the global MWC stream */
 struct JitterSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_JITTER; } };
+/* BlueNoiseSamplingTile (Sampling.cpp:421-466): tiles of 40/sqrt(spp) output pixels, per-sample Kaiser splat */
+struct BlueNoiseSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_BLUENOISE; } };
 struct FastBlueSamplingTile : SamplingTile {
     FastBlueSamplingTile() { nVenera = 0; }
     void QIndex1(int prime);

@@ -239,3 +239,25 @@ def test_jitter_tile_restatement(rt, oracle):
     fb = oracle.OracleScene(fbs.desc)
     b, _, _ = fb.render(40, 24, 4, rd, rt.RtStats(), threads=2)
     assert np.abs(a - b).mean() < 0.02 and np.abs(a).mean() > 0.001
+
+
+def test_bluenoise_tile_restatement(rt, oracle):
+    """BlueNoiseSamplingTile restated: ceil(W/fSqrt) x ceil(H/fSqrt) tiles of 1600 samples, positions inside their
+    tile, auxiliary dimensions inside the unit disk and repeating with period 128; the image agrees with the FastBlue
+    tile's up to sampling noise."""
+    raw = rt.FrontScene("S0", "bluenoise", optimize=False)
+    osc = oracle.OracleScene(raw.desc)
+    w, h, spp = 50, 30, 4
+    o8, xy, tot = osc.bluenoise_samples(w, h, spp, 0, 3 * 2 * 1600)
+    assert tot == 3 * 2 * 1600                                  # fSqrt = 20
+    tile = np.arange(tot) // 1600
+    assert np.all((xy[:, 0] >= 20 * (tile // 2)) & (xy[:, 0] <= 20 * (tile // 2 + 1)))        # the tile holds points at exactly 1.0
+    assert np.all((xy[:, 1] >= 20 * (tile % 2)) & (xy[:, 1] <= 20 * (tile % 2 + 1)))
+    assert np.all(np.hypot(o8[:, 2::2], o8[:, 3::2]) <= 1.0 + 1e-9) and np.array_equal(o8[:128, 2:], o8[128:256, 2:])
+    assert np.allclose(o8[:, 0], xy[:, 0] / 50) and np.allclose(o8[:, 1], (xy[:, 1] + 10) / 50)
+    rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
+    a, _, n = osc.render(w, h, spp, rd, rt.RtStats(), threads=2)
+    assert n == tot
+    fbs = rt.FrontScene("S0", "fastblue", optimize=False)
+    b, _, _ = oracle.OracleScene(fbs.desc).render(w, h, spp, rd, rt.RtStats(), threads=2)
+    assert np.abs(a - b).mean() < 0.02 and np.abs(a).mean() > 0.001

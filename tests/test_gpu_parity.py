@@ -332,6 +332,33 @@ def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
     assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
 
 
+@pytest.mark.parametrize("scene,w,h,spp", [("S0", 100, 60, 4), ("S1", 72, 96, 3), ("S2", 90, 50, 1), ("S0", 12, 10, 16)])
+def test_bluenoise_tile_matches_oracle(gpu, oracle, scene, w, h, spp):
+    """a1 BlueNoiseSamplingTile (Sampling.cpp:427-466): tiles of 40/sqrt(spp) output pixels at accumulated positions,
+    auxiliary dimensions from DiskSamples128, every sample splat through the float Kaiser filter (Image.cpp:1203-1236)
+    into an image that mirrors at its borders, then Normalize.  Sample positions are bit exact; the per-pixel gather
+    adds in the reference's order, so the image differs from the CPU's only through sinf (and the scene's own libm
+    calls): a tolerance, stated.  A band rendered on its own equals the same rows of the frame bit for bit."""
+    opt, raw, g, o = _pair(gpu, oracle, scene, "bluenoise")
+    _, _, tot = g.samples(w, h, spp, 0, 0)
+    s8, xy, _ = g.samples(w, h, spp, 0, tot)
+    o8, oxy, tot2 = o.bluenoise_samples(w, h, spp, 0, tot)
+    assert tot == tot2 and tot % 1600 == 0 and np.array_equal(s8, o8) and np.array_equal(xy, oxy)
+    assert np.all(np.hypot(s8[:, 2], s8[:, 3]) <= 1.0 + 1e-9)
+    img, st = g.render(w, h, spp)
+    rd = gpu.RtRenderDesc(w, h, float(spp), 0, 0)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(w, h, spp, rd, ost, threads=4)
+    assert st.samples == n == tot and st.rays() == ost.rays()
+    assert np.abs(img - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(img - ref).max()
+    if h >= 40:
+        band, _ = g.render(w, h, spp, row0=h // 3, row1=2 * h // 3)
+        assert np.array_equal(band[:, h // 3:2 * h // 3, :], img[:, h // 3:2 * h // 3, :])
+        top, _ = g.render(w, h, spp, row0=0, row1=7)
+        bot, _ = g.render(w, h, spp, row0=h - 5, row1=h)
+        assert np.array_equal(top[:, :7, :], img[:, :7, :]) and np.array_equal(bot[:, h - 5:, :], img[:, h - 5:, :])
+
+
 @pytest.mark.parametrize("scene", ["S0", "S2", SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC],
                          ids=["stereographic", "aperture", "perspective", "orthographic"])
 def test_every_camera_emits_the_oracles_rays(gpu, oracle, scene):
