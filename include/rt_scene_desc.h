@@ -132,6 +132,7 @@ typedef struct RtStats {
     double  seconds;                /* wall time of the render call */
     double  seconds_trace;          /* of which: sample generation + intersect + shading */
     double  seconds_reconstruct;    /* of which: splat + resample + normalise */
+    int64_t refined_blocks;         /* AdaptiveBlueSamplingTile: 20x20 blocks that got a second pass (their rays are counted above) */
 } RtStats;
 
 #ifdef __cplusplus

@@ -645,7 +645,7 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
     Scene *s = (Scene *)h;
     auto t0 = std::chrono::steady_clock::now();
     int W = rd->width, H = rd->height;
-    long ns = 0, np = 0, nsh = 0, nsec = 0;
+    long ns = 0, np = 0, nsh = 0, nsec = 0, refined = 0;
     if (threads < 1) threads = 1;
     if (s->sampler_type == RT_SAMPLER_TEST) {
         int n = W, nHi = H;
@@ -741,6 +741,7 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
         normalize_image(im, wt);
         memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
     } else {
+        const bool adaptive = s->sampler_type == RT_SAMPLER_ADAPTIVEBLUE;
         double spp = rd->spp;
         int nW = int(W * sqrt(spp) + 0.5), nH = int(H * sqrt(spp) + 0.5);
         Img im2, wt2;
@@ -778,15 +779,80 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
         }
         ns = ntile * RT_BLUE_N;
         if (sample_rgb_out) memcpy(sample_rgb_out, &rgb[0], sizeof(Rgb) * rgb.size());
-        Img im, wt;
-        image_resample(im, W, H, im2);
-        image_resample(wt, W, H, wt2);
-        normalize_image(im, wt);
-        memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
+        if (adaptive) {
+            /* AdaptiveBlueSamplingTile::Render, Sampling.cpp:619-679 (the base pass above is its lines 592-617; the two
+               diagnostic BMP files it writes on the way are not produced) */
+            Img det;
+            det.alloc(nW, nH, 1);                       /* WRAP_MIRROR, Sampling.cpp:580 */
+            for (int j = 0; j < nH; j++)
+                for (int i = 0; i < nW; i++) {
+                    double f00 = 0.212649390101432f * im2.at(i, j, 0) + 0.715169131755828f * im2.at(i, j, 1) + 0.0721815153956413f * im2.at(i, j, 2);
+                    det.at(i, j, 0) = float(f00);
+                }
+            normalize_image(det, wt2);
+            auto get = [&](int i, int j) -> double { return det.at(wrap_mirror(i, nW), wrap_mirror(j, nH), 0); };
+            for (int j = 0; j < nH; j++)                /* in place, like the reference */
+                for (int i = 0; i < nW; i++) {
+                    double f00 = get(i + 0, j + 0), f01 = get(i + 0, j + 1), f10 = get(i + 1, j + 0), f11 = get(i + 1, j + 1);
+                    double g1 = f00 - f11, g2 = f01 - f10, sum = f00 + f01 + f10 + f11, gv;
+                    if (sum > 0.0) gv = sqrt(g1 * g1 + g2 * g2) / sum * 1.0; else gv = 0.0;
+                    det.at(i, j, 0) = float(gv);
+                }
+            const int B = RT_BLUE_NSQRT / 2, HYST = 2;
+            std::vector<std::pair<int, int> > blocks;
+            for (int j = 0; j < nH; j += B)
+                for (int i = 0; i < nW; i += B) {
+                    double maxg = 0;
+                    for (int is = i - HYST; is < i + B + HYST; is++)
+                        for (int js = j - HYST; js < j + B + HYST; js++) {
+                            double gv = get(is, js);
+                            if (gv > maxg) maxg = gv;
+                        }
+                    if (maxg > 0.30) blocks.push_back(std::make_pair(i, j));
+                }
+            refined = (long)blocks.size();
+            std::vector<Rgb> rgb2(blocks.size() * RT_BLUE_N);
+            auto pos2 = [&](size_t b, int k, double &vx, double &vy) {
+                vx = g_t.blue[2 * k] * RT_BLUE_NSQRT / 2 + double(blocks[b].first);
+                vy = g_t.blue[2 * k + 1] * RT_BLUE_NSQRT / 2 + double(blocks[b].second);
+            };
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(+:np,nsh,nsec)
+            for (long b = 0; b < (long)blocks.size(); b++) {
+                Ctx cx;
+                for (int k = 0; k < RT_BLUE_N; k++) {
+                    double vx, vy;
+                    pos2((size_t)b, k, vx, vy);
+                    cx.aux[0] = 2.0 * g_t.blue[2 * s->qi3[k % RT_BLUE_N]] - 1.0;
+                    cx.aux[1] = 2.0 * g_t.blue[2 * s->qi3[k % RT_BLUE_N] + 1] - 1.0;
+                    cx.aux[2] = 2.0 * g_t.blue[2 * s->qi2[k % RT_BLUE_N]] - 1.0;
+                    cx.aux[3] = 2.0 * g_t.blue[2 * s->qi2[k % RT_BLUE_N] + 1] - 1.0;
+                    cx.aux[4] = cx.aux[2];
+                    cx.aux[5] = cx.aux[3];
+                    rgb2[(size_t)b * RT_BLUE_N + k] = sample_rgb(*s, (vx + ax) / fSize, (vy + ay) / fSize, cx);
+                }
+                np += cx.n_primary; nsh += cx.n_shadow; nsec += cx.n_secondary;
+            }
+            for (size_t b = 0; b < blocks.size(); b++)
+                for (int k = 0; k < RT_BLUE_N; k++) {
+                    double vx, vy;
+                    pos2(b, k, vx, vy);
+                    fast_splat(im2, wt2, rgb2[b * RT_BLUE_N + k], vx, vy);
+                }
+        }
+        if (adaptive && spp == 1.0) {                   /* Sampling.cpp:687-692 */
+            normalize_image(im2, wt2);
+            memcpy(planes, &im2.px[0], sizeof(float) * im2.px.size());
+        } else {
+            Img im, wt;
+            image_resample(im, W, H, im2);
+            image_resample(wt, W, H, wt2);
+            normalize_image(im, wt);
+            memcpy(planes, &im.px[0], sizeof(float) * im.px.size());
+        }
     }
     if (st) {
         memset(st, 0, sizeof *st);
-        st->samples = ns; st->rays_primary = np; st->rays_shadow = nsh; st->rays_secondary = nsec;
+        st->samples = ns; st->rays_primary = np; st->rays_shadow = nsh; st->rays_secondary = nsec; st->refined_blocks = refined;
         st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return (int)ns;

@@ -49,7 +49,7 @@ class RtRenderDesc(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("rays_primary", C.c_int64), ("rays_shadow", C.c_int64),
                 ("rays_secondary", C.c_int64), ("hit_overflow", C.c_int64), ("seconds", C.c_double),
-                ("seconds_trace", C.c_double), ("seconds_reconstruct", C.c_double)]
+                ("seconds_trace", C.c_double), ("seconds_reconstruct", C.c_double), ("refined_blocks", C.c_int64)]
 
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_secondary

@@ -47,6 +47,9 @@ RT_DEV Spec spec_fetch(const float *base, size_t cap, size_t idx) { Spec s; for 
 RT_DEV void d3_store(double *base, size_t cap, int field, size_t idx, const D3 &v) { nt_store(&base[(size_t)field * cap + idx], v.x); nt_store(&base[(size_t)(field + 1) * cap + idx], v.y); nt_store(&base[(size_t)(field + 2) * cap + idx], v.z); }
 RT_DEV D3 d3_fetch(const double *base, size_t cap, int field, size_t idx) { return d3(nt_load(&base[(size_t)field * cap + idx]), nt_load(&base[(size_t)(field + 1) * cap + idx]), nt_load(&base[(size_t)(field + 2) * cap + idx])); }
 
+#define RT_ADAPT_BLOCK 20       /* BLUE_NSQRT/NSQRT1, Sampling.cpp:649 */
+#define RT_ADAPT_HYST  2        /* HYSTERESIS */
+
 /* ------------------------------------------------------------------ sample generation + camera */
 __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s, double *pos2, double *v2, double *aux)
 {
@@ -91,7 +94,24 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
         aux[4] = S.disk128[2 * q5]; aux[5] = S.disk128[2 * q5 + 1];
         return;
     }
-    /* FastBlueSamplingTile::Render, Sampling.cpp:498-517: tile x outer, tile y inner, i innermost */
+    if (g.sampler == RT_SAMPLER_ADAPTIVEBLUE && g.ad_list) {    /* refinement pass, Sampling.cpp:660-669 */
+        const int blk = g.ad_list[s / RT_BLUE_N], k = (int)(s % RT_BLUE_N);
+        const double vtx = (double)((blk % g.ad_bx) * RT_ADAPT_BLOCK), vty = (double)((blk / g.ad_bx) * RT_ADAPT_BLOCK);
+        /* v = g_rgvBlueNoise[k]*BLUE_NSQRT/NSQRT1 + vTile */
+        const double vx = S.blue[2 * k] * (double)RT_BLUE_NSQRT / 2.0 + vtx, vy = S.blue[2 * k + 1] * (double)RT_BLUE_NSQRT / 2.0 + vty;
+        pos2[0] = vx; pos2[1] = vy;
+        v2[0] = (vx + g.adjust_x) / g.size; v2[1] = (vy + g.adjust_y) / g.size;
+        const int q3 = S.qi3[k % RT_BLUE_N], q2 = S.qi2[k % RT_BLUE_N];
+        aux[0] = 2.0 * S.blue[2 * q3] - 1.0;
+        aux[1] = 2.0 * S.blue[2 * q3 + 1] - 1.0;
+        aux[2] = 2.0 * S.blue[2 * q2] - 1.0;
+        aux[3] = 2.0 * S.blue[2 * q2 + 1] - 1.0;
+        aux[4] = aux[2];
+        aux[5] = aux[3];
+        return;
+    }
+    /* FastBlueSamplingTile::Render, Sampling.cpp:498-517 (and the base pass of the adaptive tile, :592-617): tile x outer,
+       tile y inner, i innermost */
     const uint32_t tile = (uint32_t)(s / RT_BLUE_N);      /* < 2^31 tiles (checked by the host) */
     int i = (int)(s - (int64_t)tile * RT_BLUE_N);
     const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
@@ -897,6 +917,116 @@ __global__ void __launch_bounds__(256) k_kaiser_gather(const RtDevScene Sv, RtSa
     if (w) { r /= w; gg /= w; b /= w; }                 /* Image::Normalize */
     const size_t o = (size_t)py * W + px, plane = (size_t)W * H;
     planes[o] = r; planes[plane + o] = gg; planes[2 * plane + o] = b;
+}
+
+/* ------------------------------------------------------------------ AdaptiveBlueSamplingTile, Sampling.cpp:619-679
+ * After the base pass (a FastBlue pass) the reference computes the normalised luminance of the supersampled image,
+ * its Roberts-cross gradient relative to the local sum, and refines every 20 x 20 block whose (24 x 24, mirrored)
+ * neighbourhood holds a gradient above 0.30 with 1600 more samples splat into the same image.  Rows are local:
+ * arrays hold supersample rows [y0, y0 + rows). */
+__global__ void __launch_bounds__(256) k_adapt_luminance(const float *im2, const float *wt2, int nW, int rows, float *lum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
+    if (i >= nW) return;
+    const size_t o = (size_t)jl * nW + i, plane = (size_t)rows * nW;
+    float l = 0.212649390101432f * im2[o] + 0.715169131755828f * im2[plane + o] + 0.0721815153956413f * im2[2 * plane + o];    /* DisplayRGB::Luminance, Image.h:75 */
+    const float w = wt2[o];
+    if (w) l /= w;                                      /* imDetect.Normalize(&im2Weight) */
+    lum[o] = l;
+}
+/* the reference overwrites imDetect in place, row by row; every value it reads (right, below, diagonal; the mirrored
+   index n maps to n - 1) is still a luminance at that moment, so out of place with clamped reads is the same */
+__global__ void __launch_bounds__(256) k_adapt_roberts(const float *lum, int nW, int nH, int y0, int rows, float *grad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, jl = blockIdx.y;
+    if (i >= nW) return;
+    const int j = y0 + jl;
+    int j1 = j + 1 < nH ? j + 1 : nH - 1;
+    const int i1 = i + 1 < nW ? i + 1 : nW - 1;
+    float out = 0.0f;
+    if (j1 - y0 < rows) {                               /* the last local row of a band has no row below it and is never needed */
+        const double f00 = lum[(size_t)jl * nW + i], f01 = lum[(size_t)(j1 - y0) * nW + i], f10 = lum[(size_t)jl * nW + i1], f11 = lum[(size_t)(j1 - y0) * nW + i1];
+        const double g1 = f00 - f11, g2 = f01 - f10, sum = f00 + f01 + f10 + f11;
+        double gv;
+        if (sum > 0.0) gv = sqrt(g1 * g1 + g2 * g2) / sum * 1.0; else gv = 0.0;
+        out = (float)gv;
+    }
+    grad[(size_t)jl * nW + i] = out;
+}
+/* one wave per block: the maximum over its neighbourhood, flag = maxg > THRESHOLD1 */
+__global__ void __launch_bounds__(64) k_adapt_blocks(const float *grad, int nW, int nH, int y0, int rows, int bx, int bj0, int *flags)
+{
+    const int bi = blockIdx.x, bj = bj0 + blockIdx.y, span = RT_ADAPT_BLOCK + 2 * RT_ADAPT_HYST;
+    float m = 0.0f;
+    for (int e = threadIdx.x; e < span * span; e += 64) {
+        const int is = mirror_index(bi * RT_ADAPT_BLOCK - RT_ADAPT_HYST + e % span, nW), js = mirror_index(bj * RT_ADAPT_BLOCK - RT_ADAPT_HYST + e / span, nH);
+        const int jl = js - y0;
+        if (jl < 0 || jl >= rows) continue;             /* cannot happen: the host sizes the row range for it */
+        const float v = grad[(size_t)jl * nW + is];
+        if (v > m) m = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(m, o, 64); if (v > m) m = v; }
+    if (threadIdx.x == 0) flags[(size_t)bj * bx + bi] = ((double)m > 0.30) ? 1 : 0;
+}
+/* refinement splats: FastSplatRGB of the refined blocks' samples, added to the base pass's sums in the reference's
+   order (block row outer, block column inner, sample index) */
+__global__ void __launch_bounds__(256) k_splat_gather_refine(const RtDevScene Sv, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
+                                                             int y0, int y1, float *im2 /*[3][rows][nW]*/, float *wt2 /*[rows][nW]*/)
+{
+    const RtDevScene &S = Sv;
+    const int px = blockIdx.x * blockDim.x + threadIdx.x, py = y0 + blockIdx.y, B = RT_ADAPT_BLOCK;
+    if (px >= g.nW || py >= y1) return;
+    const size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
+    float r = im2[o], gg = im2[rows * g.nW + o], b = im2[2 * rows * g.nW + o], w = wt2[o];
+    const int bcx = px / B, bcy = py / B;
+    bool any = false;
+    for (int bj = bcy - 1; bj <= bcy + 1; bj++) {
+        if (bj < g.ad_bj0 || bj > g.ad_bj1) continue;
+        const int ly = py - bj * B;
+        if (ly < -1 || ly > B) continue;
+        for (int bi = bcx - 1; bi <= bcx + 1; bi++) {
+            if (bi < 0 || bi >= g.ad_bx) continue;
+            const int lx = px - bi * B;
+            if (lx < -1 || lx > B) continue;
+            const int ord = g.ad_ord[bj * g.ad_bx + bi];
+            if (ord < 0) continue;
+            const int cell = (ly + 1) * (B + 2) + (lx + 1);
+            const int e0 = T.offsets[cell], e1 = T.offsets[cell + 1];
+            const int64_t sbase = (int64_t)ord * RT_BLUE_N;
+            for (int e = e0; e < e1; e++) {
+                const int k = T.entries[e];
+                double x = S.blue[2 * k] * (double)RT_BLUE_NSQRT / 2.0 + (double)(bi * B);
+                double y = S.blue[2 * k + 1] * (double)RT_BLUE_NSQRT / 2.0 + (double)(bj * B);
+                x -= 0.5; y -= 0.5;
+                const double fx = floor(x), fy = floor(y);
+                const int i1 = (int)fx, j1 = (int)fy;
+                const double dx = x - fx, dy = y - fy;
+                double wx, wy;
+                if (px == i1) wx = 1.0 - dx; else if (px == i1 + 1) wx = dx; else continue;
+                if (py == j1) wy = 1.0 - dy; else if (py == j1 + 1) wy = dy; else continue;
+                const float *c = sample_rgb + 3 * (sbase + k);
+                r += (float)((double)(float)((double)c[0] * wx) * wy);
+                gg += (float)((double)(float)((double)c[1] * wx) * wy);
+                b += (float)((double)(float)((double)c[2] * wx) * wy);
+                w += (float)(wx * wy);
+                any = true;
+            }
+        }
+    }
+    if (any) { im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b; wt2[o] = w; }
+}
+/* fSamplesPerPixel == 1.0 (Sampling.cpp:687-692): the supersampled image IS the output; Normalize by its weights */
+__global__ void __launch_bounds__(256) k_adapt_direct(const float *im2, const float *wt2, int width, int height, int y0, int rows, int row0, int row1, float *planes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = row0 + blockIdx.y;
+    if (i >= width || j >= row1) return;
+    const size_t o = (size_t)(j - y0) * width + i, plane = (size_t)rows * width;
+    const float w = wt2[o];
+    for (int k = 0; k < 3; k++) {
+        float v = im2[k * plane + o];
+        if (w) v /= w;
+        planes[((size_t)k * height + j) * width + i] = v;
+    }
 }
 
 /* Resample (Sampling.cpp:131-184), WRAP_CLAMP.  src: [planes][src_rows][src_n] -> dst laid out [planes][src_rows][dst_n] */

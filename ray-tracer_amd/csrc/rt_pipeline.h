@@ -55,6 +55,11 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     /* BLUENOISE (Sampling.cpp:427-466): tiles of bn_sqrt output pixels at the accumulated positions bn_tx[tiles_x], bn_ty[tiles_y] */
     double  bn_sqrt;
     const double *bn_tx, *bn_ty;
+    /* ADAPTIVEBLUE (Sampling.cpp:562-694): 20x20 supersample-pixel blocks, ad_bx per row; block rows [ad_bj0, ad_bj1] are
+       analysed by this call; ad_list[n] = refined block ids in the reference's order (set for the refinement pass only),
+       ad_ord[block] = position in that list or -1 */
+    int     ad_bx, ad_by, ad_bj0, ad_bj1;
+    const int *ad_list, *ad_ord;
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;

@@ -533,6 +533,10 @@ struct FastBlueSamplingTile : SamplingTile {
     int DeviceSampler() const { return RT_SAMPLER_FASTBLUE; }
 };
 
+/* AdaptiveBlueSamplingTile (Sampling.cpp:550-709): a FastBlue pass, then 1600 more samples in every 20x20 block of the
+   supersampled image whose neighbourhood has a Roberts gradient above 0.30 */
+struct AdaptiveBlueSamplingTile : FastBlueSamplingTile { int DeviceSampler() const { return RT_SAMPLER_ADAPTIVEBLUE; } };
+
 /* ------------------------------------------------------------------- scene (RayTracer2020.h:188) ---- */
 struct RayTracer {
     Solid *psModel; AmbientLight *plAmbient; PointLight *plPointLights; Camera *pcCamera; SamplingTile *psSample;

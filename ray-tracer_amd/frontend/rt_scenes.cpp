@@ -373,6 +373,7 @@ struct Parser {
                 if (k == "test") rt->psSample = new TestSamplingTile;
                 else if (k == "jitter") rt->psSample = new JitterSamplingTile;
                 else if (k == "bluenoise") rt->psSample = new BlueNoiseSamplingTile;
+                else if (k == "adaptive") { rt->psSample = new AdaptiveBlueSamplingTile; if (!peek_close()) rt->psSample->QIndex1((int)num()); }
                 else if (k == "fastblue") { rt->psSample = new FastBlueSamplingTile; if (!peek_close()) rt->psSample->QIndex1((int)num()); }
                 else fail("unknown sampler " + k);
             }
@@ -415,6 +416,7 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     if (sampler && !strcmp(sampler, "test")) s->rt.psSample = new TestSamplingTile;
     else if (sampler && !strcmp(sampler, "jitter")) s->rt.psSample = new JitterSamplingTile;
     else if (sampler && !strcmp(sampler, "bluenoise")) s->rt.psSample = new BlueNoiseSamplingTile;
+    else if (sampler && !strcmp(sampler, "adaptive")) s->rt.psSample = new AdaptiveBlueSamplingTile;
     else if (sampler && !strcmp(sampler, "fastblue") && !(s->rt.psSample && s->rt.psSample->DeviceSampler() == RT_SAMPLER_FASTBLUE)) s->rt.psSample = new FastBlueSamplingTile;
     if (!s->rt.psSample) s->rt.psSample = new TestSamplingTile;
     if (!s->rt.pcCamera) s->rt.pcCamera = new StereographicCamera(Point3(0.0, 0.0, 8.0), 70.0);

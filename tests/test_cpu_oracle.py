@@ -261,3 +261,21 @@ def test_bluenoise_tile_restatement(rt, oracle):
     fbs = rt.FrontScene("S0", "fastblue", optimize=False)
     b, _, _ = oracle.OracleScene(fbs.desc).render(w, h, spp, rd, rt.RtStats(), threads=2)
     assert np.abs(a - b).mean() < 0.02 and np.abs(a).mean() > 0.001
+
+
+def test_adaptive_tile_restatement(rt, oracle):
+    """AdaptiveBlueSamplingTile restated: the base pass is the FastBlue pass (same return value), refinement happens
+    only where there is contrast (some blocks, not all), costs 1600 primary rays per block, and moves the image towards
+    a higher-rate FastBlue render at the refined places without touching flat regions."""
+    w, h, spp = 60, 40, 4
+    rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
+    ads = rt.FrontScene("S0", "adaptive", optimize=False)
+    fbs = rt.FrontScene("S0", "fastblue", optimize=False)
+    sta, stf = rt.RtStats(), rt.RtStats()
+    a, _, na = oracle.OracleScene(ads.desc).render(w, h, spp, rd, sta, threads=2)
+    b, _, nb = oracle.OracleScene(fbs.desc).render(w, h, spp, rd, stf, threads=2)
+    assert na == nb and stf.refined_blocks == 0
+    nblk = (120 // 20) * (80 // 20)
+    assert 0 < sta.refined_blocks < nblk and sta.rays_primary == stf.rays_primary + 1600 * sta.refined_blocks
+    changed = np.abs(a - b).max(axis=0) > 0
+    assert 0.02 < changed.mean() < 0.98 and np.abs(a - b).max() < 0.5

@@ -359,6 +359,33 @@ def test_bluenoise_tile_matches_oracle(gpu, oracle, scene, w, h, spp):
         assert np.array_equal(top[:, :7, :], img[:, :7, :]) and np.array_equal(bot[:, h - 5:, :], img[:, h - 5:, :])
 
 
+@pytest.mark.parametrize("scene,w,h,spp,tol", [("S0", 100, 60, 4, 0.0), ("S0", 120, 90, 1, 0.0), ("S1", 80, 110, 2.25, 2e-5), ("S0", 33, 21, 9, 0.0)])
+def test_adaptive_tile_matches_oracle(gpu, oracle, scene, w, h, spp, tol):
+    """a1 AdaptiveBlueSamplingTile (Sampling.cpp:562-694): FastBlue base pass, normalised luminance, Roberts gradient
+    over the local sum, 20 x 20 blocks refined where the mirrored 24 x 24 neighbourhood exceeds 0.30, refinement splats
+    added after the base pass's in block order, resampling (or, at exactly 1 spp, the supersampled image handed over).
+    Same blocks refined, same ray counts, image bit exact where the scene has no libm call on its path; a band rendered
+    on its own (which re-derives the block decisions from a row range with halo) equals the same rows of the frame."""
+    opt, raw, g, o = _pair(gpu, oracle, scene, "adaptive")
+    img, st = g.render(w, h, spp)
+    rd = gpu.RtRenderDesc(w, h, float(spp), 0, 0)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(w, h, spp, rd, ost, threads=4)
+    assert st.samples == n and st.refined_blocks == ost.refined_blocks and st.rays() == ost.rays()
+    nW, nH = int(w * np.sqrt(spp) + 0.5), int(h * np.sqrt(spp) + 0.5)
+    nblk = ((nW + 19) // 20) * ((nH + 19) // 20)
+    assert 0 < st.refined_blocks < nblk                # edges refined, flat regions not
+    assert st.rays_primary == n + 1600 * st.refined_blocks
+    if tol == 0.0:
+        assert np.array_equal(img, ref)
+    else:
+        assert np.abs(img - ref).max() <= tol
+    for a, b in ((h // 3, 2 * h // 3), (0, 9), (h - 6, h)):
+        band, bst = g.render(w, h, spp, row0=a, row1=b)
+        assert np.array_equal(band[:, a:b, :], img[:, a:b, :]), (a, b)
+        assert bst.refined_blocks <= st.refined_blocks
+
+
 @pytest.mark.parametrize("scene", ["S0", "S2", SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC],
                          ids=["stereographic", "aperture", "perspective", "orthographic"])
 def test_every_camera_emits_the_oracles_rays(gpu, oracle, scene):
