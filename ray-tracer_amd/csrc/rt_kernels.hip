@@ -200,11 +200,25 @@ RT_DEV DRay root_ray_for_cull(const RtDevScene &S, const RtSampleGrid &g, int64_
     return r;
 }
 
-RT_DEV void root_frame(const RtPipe &P, int f, int k, const DRay &r, const double *aux)
+/* the auxiliary dimensions of root sample k that later stages can ask for */
+RT_DEV void aux_store(const RtDevScene &S, const RtPipe &P, int k, const double *aux)
+{
+    if (S.aux_light) { P.aux[(size_t)2 * P.ncap + k] = aux[2]; P.aux[(size_t)3 * P.ncap + k] = aux[3]; }
+    if (S.aux_tex) { P.aux[(size_t)4 * P.ncap + k] = aux[4]; P.aux[(size_t)5 * P.ncap + k] = aux[5]; }
+}
+template <bool LITE>
+RT_DEV void aux_load(const RtDevScene &S, const RtPipe &P, int root, double *aux)
+{
+    for (int i = 0; i < 6; i++) aux[i] = 0.0;
+    if (S.aux_light) { aux[2] = P.aux[(size_t)2 * P.ncap + root]; aux[3] = P.aux[(size_t)3 * P.ncap + root]; }
+    if constexpr (!LITE) if (S.aux_tex) { aux[4] = P.aux[(size_t)4 * P.ncap + root]; aux[5] = P.aux[(size_t)5 * P.ncap + root]; }   /* LITE hands textured hits to FULL */
+}
+
+RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const DRay &r, const double *aux)
 {
     d3_store(P.f_ray, P.fcap, 0, f, r.org);
     d3_store(P.f_ray, P.fcap, 3, f, r.dir);
-    for (int i = 0; i < 6; i++) P.aux[(size_t)i * P.ncap + k] = aux[i];
+    aux_store(S, P, k, aux);
     P.f_parent[f] = -1;
     P.f_root[f] = k;
     P.f_flags[f] = 0;
@@ -218,7 +232,7 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleG
     double aux[6];
     DRay r;
     root_ray(Sv, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
-    root_frame(P, k, k, r, aux);
+    root_frame(Sv, P, k, k, r, aux);
 }
 
 /* The same for scenes with a root cull (RtDevScene.root_cull): rays that miss every conservative box of the
@@ -268,7 +282,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         double aux[6];
         DRay r;
         root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
-        root_frame(P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux);
+        root_frame(S, P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux);
     }
 }
 
@@ -319,7 +333,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
         ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
         ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
         int root = P.f_root[f];
-        for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
+        aux_load<LITE>(S, P, root, aux);
         Arena A;
         int start;
         int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start);
@@ -334,6 +348,8 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
         if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
         double t = 0.0;
         Spec tr = spec_const(1.0f), R = spec_const(0.0f);
+        int r_state = 0;                /* 0: R is zero, 1: R is the boundary's ambient term alone, 2: anything else */
+        bool tr_one = true;
         for (; i < count && !bail; i++) {
             ShadeHit h;
             transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
@@ -341,6 +357,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
             const RtMaterialDev &mp = S.mats[pm];
             if (mp.luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
                 R = spec_load(mp.color);
+                r_state = 2;
                 flags |= FR_FINAL;
                 break;
             }
@@ -351,6 +368,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
                     propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
                     tr = tr * ptr;
                     R = R + pst;
+                    r_state = 2; tr_one = false;
                 }
             }
             const RtMaterialDev &mh = S.mats[h.mat];
@@ -359,11 +377,13 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
                 double fNE, F = 0.0, fNT = 0.0;
                 consistent_normal(ray, h, vE, cvN, fNE);
                 Spec color = spec_load(mh.color);
+                bool color_is_mat = true;
                 if (spectral_metal(mh.luster)) {                /* Q3 */
                     if constexpr (LITE) { bail = true; break; }
                     else {
                         color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC + RT_NSPEC);
                         F = 1.0;
+                        color_is_mat = false;
                     }
                 } else
                     fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
@@ -371,6 +391,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
                 if (S.has_ambient && rough != RT_SURF_POLISHED) {
                     Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
                     R = R + color * E;
+                    r_state = (r_state == 0 && color_is_mat) ? 1 : 2;
                 }
                 Ppt = ray_at(ray, h.t);
                 /* which lights get a shadow ray (Shade.cpp:477-481) */
@@ -395,8 +416,8 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
                 P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
                 P.f_geo[(size_t)GEO_ETA * P.fcap + f] = mp.refr / mh.refr;
                 P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
-                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh.luster;
-                spec_store(P.f_color, P.fcap, f, color);
+                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh.luster | ((int)h.mat << 8);
+                if (color_is_mat) flags |= FR_COLOR_MAT; else spec_store(P.f_color, P.fcap, f, color);
                 t = h.t;
                 pm = h.mat;
                 break;
@@ -415,8 +436,8 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
             }
         }
         if (!bail) {
-            spec_store(P.f_R, P.fcap, f, R);
-            spec_store(P.f_tr, P.fcap, f, tr);
+            if (r_state == 0) flags |= FR_R_ZERO; else if (r_state == 1) flags |= FR_R_AMBIENT; else spec_store(P.f_R, P.fcap, f, R);
+            if (tr_one) flags |= FR_TR_ONE; else spec_store(P.f_tr, P.fcap, f, tr);
         }
     }
     if constexpr (LITE) {
@@ -483,7 +504,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_SHADOW_THREADS : 256) k_shadow(
         const RtLightDev &l = S.lights[P.s_light[s]];
         double aux[6];
         int root = P.s_root[s];
-        for (int i = 0; i < 6; i++) aux[i] = P.aux[(size_t)i * P.ncap + root];
+        aux_load<LITE>(S, P, root, aux);
         double r2 = dot(ray.dir, ray.dir);
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
         Arena A;
@@ -563,15 +584,21 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
         depth = FR_DEPTH(flags);
         if (flags & FR_BOUNDARY) {
             int root = P.f_root[f];
-            double uL = P.aux[(size_t)2 * P.ncap + root], vL_ = P.aux[(size_t)3 * P.ncap + root];
+            double uL = 0.0, vL_ = 0.0;
+            if (S.aux_light) { uL = P.aux[(size_t)2 * P.ncap + root]; vL_ = P.aux[(size_t)3 * P.ncap + root]; }
             Ppt = d3_fetch(P.f_geo, P.fcap, GEO_P, f);
             D3 cvN = d3_fetch(P.f_geo, P.fcap, GEO_N, f), vE = d3_fetch(P.f_geo, P.fcap, GEO_E, f), hn = d3_fetch(P.f_geo, P.fcap, GEO_HN, f);
             double fNE = P.f_geo[(size_t)GEO_FNE * P.fcap + f], F = P.f_geo[(size_t)GEO_F * P.fcap + f];
             double fNT = P.f_geo[(size_t)GEO_FNT * P.fcap + f], eta = P.f_geo[(size_t)GEO_ETA * P.fcap + f];
             int rough = P.f_ids[(size_t)IDS_ROUGH * P.fcap + f], luster = P.f_ids[(size_t)IDS_LUSTER * P.fcap + f];
+            const int mat = luster >> 8;
+            luster &= 0xFF;
             int base = P.f_ids[(size_t)IDS_SHBASE * P.fcap + f];
             unsigned mask = (unsigned)P.f_ids[(size_t)IDS_SHMASK * P.fcap + f];
-            Spec color = spec_fetch(P.f_color, P.fcap, f), R = spec_fetch(P.f_R, P.fcap, f);
+            Spec color = (flags & FR_COLOR_MAT) ? spec_load(S.mats[mat].color) : spec_fetch(P.f_color, P.fcap, f), R;
+            if (flags & FR_R_ZERO) R = spec_const(0.0f);
+            else if (flags & FR_R_AMBIENT) { Spec E = spec_load(S.ambient) * RT_PI; R = spec_const(0.0f); R = R + color * E; }     /* as k_visual would have */
+            else R = spec_fetch(P.f_R, P.fcap, f);
             int k = 0;
             for (int li = 0; li < S.n_lights; li++) {
                 const RtLightDev &l = S.lights[li];
@@ -610,8 +637,8 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
         /* A frame without reflection / refraction terms is finished here: R * tr + fin, then on to its parent or its
            sample (what k_resolve would do, without another pass over the frame); the others keep R for k_resolve. */
         if (!(flags & (FR_C1 | FR_C2))) {
-            Spec R = have_R ? Rfin : spec_fetch(P.f_R, P.fcap, f);
-            if (flags & FR_BOUNDARY) R = R * spec_fetch(P.f_tr, P.fcap, f);
+            Spec R = have_R ? Rfin : ((flags & FR_R_ZERO) ? spec_const(0.0f) : spec_fetch(P.f_R, P.fcap, f));
+            if ((flags & FR_BOUNDARY) && !(flags & FR_TR_ONE)) R = R * spec_fetch(P.f_tr, P.fcap, f);
             if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
             frame_deliver(S, P, f, flags, R, out_rgb, out_spec);
             flags |= FR_DONE;
@@ -675,7 +702,7 @@ __global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, 
     if (flags & FR_BOUNDARY) {
         if (flags & FR_C1) R = R + spec_fetch(P.f_c1, P.fcap, f) * spec_fetch(P.f_w1, P.fcap, f);
         if (flags & FR_C2) R = R + spec_fetch(P.f_c2, P.fcap, f) * P.f_geo[(size_t)GEO_W2 * P.fcap + f];
-        R = R * spec_fetch(P.f_tr, P.fcap, f);
+        if (!(flags & FR_TR_ONE)) R = R * spec_fetch(P.f_tr, P.fcap, f);
     }
     if (flags & FR_FIN) R = R + spec_fetch(P.f_fin, P.fcap, f);
     frame_deliver(S, P, f, flags, R, out_rgb, out_spec);

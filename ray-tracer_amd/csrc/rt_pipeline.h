@@ -12,6 +12,11 @@
 #define FR_SLOT2      32       /* this frame is its parent's refraction child */
 #define FR_PERTURBED  64
 #define FR_DONE       128      /* resolved and delivered by k_shade (no reflection / refraction terms): k_resolve skips it */
+/* what k_visual did NOT store because k_shade / k_resolve can tell from the flag (bytes not written are the cheapest) */
+#define FR_TR_ONE     (1 << 16) /* transmittance is 1 on all bands (no propagator on the way): f_tr not written */
+#define FR_R_ZERO     (1 << 17) /* radiance gathered on the way is 0: f_R not written */
+#define FR_R_AMBIENT  (1 << 18) /* ... is exactly the ambient term colour * E of the boundary (Lights.cpp:33-37): f_R not written */
+#define FR_COLOR_MAT  (1 << 19) /* the boundary's colour is its material's (IDS_LUSTER holds luster | material << 8): f_color not written */
 #define FR_DEPTH(f)        (((f) >> 8) & 0xFF)
 #define FR_MAKE_DEPTH(d)   (((d) & 0xFF) << 8)
 #define FR_KEEP_MASK       (0xFF00 | FR_SLOT2)
@@ -32,7 +37,8 @@ typedef struct RtPipe {
     float  *f_R, *f_tr, *f_color, *f_c1, *f_c2, *f_w1, *f_fin;     /* 10 each */
     double *f_geo;              /* GEO_COUNT */
     int    *f_ids;              /* IDS_COUNT */
-    double *aux;                /* 6 x ncap: the six distributed-sampling dimensions per root sample */
+    double *aux;                /* 6 x ncap: the distributed-sampling dimensions per root sample; only the pairs the scene needs
+                                   after generation are written and read (RtDevScene.aux_light -> [2],[3]; aux_tex -> [4],[5]) */
     /* shadow rays, SoA [field][scap] */
     double *s_ray;              /* 6 */
     int    *s_light, *s_root;
