@@ -200,6 +200,76 @@ RT_DEV DRay root_ray_for_cull(const RtDevScene &S, const RtSampleGrid &g, int64_
     return r;
 }
 
+/* ------------------------------------------------------------------ tile mask (no counterpart in the reference)
+ * A blue-noise tile is a small rectangle of the image; the rays through it lie in a cone around the ray through its
+ * centre whose half-angle is reached at one of its corners (the set of image points within an angle of a direction is
+ * a disc for the stereographic camera and a conic for the perspective one -- convex, so four corners decide; for the
+ * orthographic camera the origins move instead, and the boxes are inflated by that much).  A box is replaced by its
+ * bounding sphere: cone and sphere do not meet  =>  no ray of the tile meets the box.  Conservative by construction,
+ * with slack far above the rounding of the sample positions. */
+RT_DEV bool cone_may_touch(const D3 &o, const D3 &d /*unit*/, double cos_t, double sin_t, double grow, const double lo[3], const double hi[3])
+{
+    const D3 c = d3(0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]));
+    const D3 h = d3(0.5 * (hi[0] - lo[0]), 0.5 * (hi[1] - lo[1]), 0.5 * (hi[2] - lo[2]));
+    const double r = sqrt(dot(h, h)) * (1.0 + 1e-9) + grow + 1e-9;
+    if (!(r < 1e100)) return true;                      /* unbounded or not a number: cannot exclude */
+    const D3 v = c - o;
+    const double dist2 = dot(v, v);
+    if (!(dist2 > r * r)) return true;                  /* the apex is inside the sphere */
+    const double dist = sqrt(dist2), sin_b = r / dist, cos_b = sqrt(fmax(0.0, 1.0 - sin_b * sin_b));
+    const double cos_a = dot(v, d) / dist;              /* angle between the axis and the centre of the sphere */
+    return cos_a >= cos_b * cos_t - sin_b * sin_t - 1e-9;       /* a <= b + t, with b + t < pi */
+}
+__global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSampleGrid g, unsigned char *mask)
+{
+    const RtDevScene &S = Sv;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.tiles_x * g.tiles_y_local) return;
+    const int tx = t / g.tiles_y_local, ty = t - tx * g.tiles_y_local + g.tile_y0;
+    const double N = (double)RT_BLUE_NSQRT, x0 = (double)tx * N, y0 = (double)ty * N;
+    DRay rc = camera_emit(S.cam, (x0 + 0.5 * N + g.adjust_x) / g.size, (y0 + 0.5 * N + g.adjust_y) / g.size, 0.0, 0.0);
+    const D3 dc = normalize(rc.dir);
+    double cos_t = 1.0, grow = 0.0;
+    for (int k = 0; k < 4; k++) {
+        /* samples lie in [x0, x0 + 40] x [y0, y0 + 40] (the tile holds points at exactly 1.0); a hair wider */
+        const double cx = (k & 1) ? x0 + N + 1e-6 : x0 - 1e-6, cy = (k & 2) ? y0 + N + 1e-6 : y0 - 1e-6;
+        const DRay rk = camera_emit(S.cam, (cx + g.adjust_x) / g.size, (cy + g.adjust_y) / g.size, 0.0, 0.0);
+        const double c = dot(normalize(rk.dir), dc);
+        if (c < cos_t) cos_t = c;
+        const D3 dorg = rk.org - rc.org;
+        const double m = sqrt(dot(dorg, dorg));
+        if (m > grow) grow = m;
+    }
+    cos_t = cos_t - 1e-12 - 1e-6 * (1.0 - cos_t);       /* widen the cone a little */
+    if (!(cos_t > 0.0)) { mask[t] = 1; return; }        /* absurdly wide tile: no statement */
+    const double sin_t = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
+    grow *= 1.0 + 1e-6;
+    bool touch = false;
+    if (S.root_cull == 2) touch = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi);
+    else if (S.root_cull == 1) {
+        const RtRegion &rg = S.regions[S.root_cull_arg];
+        if (rg.n_always > 0) touch = true;
+        else if (rg.bvh_root >= 0) {
+            int stack[RT_BVH_STACK], sp = 0, node = rg.bvh_root;
+            for (;;) {
+                const RtBvhNode &nd = S.bvh[node];
+                for (int k = 0; k < 4 && !touch; k++) {
+                    if (nd.child[k] == RT_BVH_EMPTY) continue;
+                    const double lo[3] = { nd.lo[0][k], nd.lo[1][k], nd.lo[2][k] }, hi[3] = { nd.hi[0][k], nd.hi[1][k], nd.hi[2][k] };
+                    if (!cone_may_touch(rc.org, dc, cos_t, sin_t, grow, lo, hi)) continue;
+                    if (nd.child[k] < 0) touch = true;
+                    else if (sp < RT_BVH_STACK) stack[sp++] = nd.child[k];
+                    else touch = true;
+                }
+                if (touch || sp == 0) break;
+                node = stack[--sp];
+            }
+        }
+    } else
+        touch = true;
+    mask[t] = touch ? 1 : 0;
+}
+
 /* the auxiliary dimensions of root sample k that later stages can ask for */
 RT_DEV void aux_store(const RtDevScene &S, const RtPipe &P, int k, const double *aux)
 {
@@ -256,8 +326,12 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         int k = k0 + it * 256 + threadIdx.x;
         bool keep = false;
         if (k < n) {
-            const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
-            keep = scene_may_hit(S, lds, r, RT_INFINITY);
+            /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
+            const bool masked = g.tile_mask && !rays_org && g.tile_mask[(first + k) / RT_BLUE_N] == 0;
+            if (!masked) {
+                const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
+                keep = scene_may_hit(S, lds, r, RT_INFINITY);
+            }
             if (!keep) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
                 if (out_spec) for (int i = 0; i < RT_NSPEC; i++) out_spec[(size_t)k * RT_NSPEC + i] = 0.0f;

@@ -66,6 +66,9 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
        ad_ord[block] = position in that list or -1 */
     int     ad_bx, ad_by, ad_bj0, ad_bj1;
     const int *ad_list, *ad_ord;
+    /* FASTBLUE: one byte per traced tile (tx * tiles_y_local + local ty), 0 = no ray through the tile can touch a box of
+       the scene (k_tile_mask): k_generate_cull finishes its 1600 samples without generating them.  Null = not used. */
+    const unsigned char *tile_mask;
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;

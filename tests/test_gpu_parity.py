@@ -332,6 +332,26 @@ def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
     assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
 
 
+@pytest.mark.parametrize("scene", ["S0", "S1", SCENE_ROW, SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC])
+def test_tile_mask_is_invisible(gpu, scene):
+    """The tile mask (a cone-against-bounding-sphere test per sampling tile that lets whole tiles end before their samples
+    are generated) is conservative: frames, bands and ray counts are bit identical with and without it, for the
+    stereographic, perspective and orthographic cameras, and it does mask something on a scene with empty borders."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    try:
+        for (w, h, spp, r0, r1) in ((160, 90, 16, 0, 0), (97, 131, 6.25, 40, 77), (400, 300, 1, 0, 0)):
+            L.rt_set_option(b"tile_mask", 1)
+            a, sa = g.render(w, h, spp, row0=r0, row1=r1)
+            L.rt_set_option(b"tile_mask", 0)
+            b, sb = g.render(w, h, spp, row0=r0, row1=r1)
+            assert np.array_equal(a, b), (w, h, spp)
+            assert sa.rays() == sb.rays() and sa.samples == sb.samples
+    finally:
+        L.rt_set_option(b"tile_mask", 1)
+
+
 @pytest.mark.parametrize("scene,w,h,spp", [("S0", 100, 60, 4), ("S1", 72, 96, 3), ("S2", 90, 50, 1), ("S0", 12, 10, 16)])
 def test_bluenoise_tile_matches_oracle(gpu, oracle, scene, w, h, spp):
     """a1 BlueNoiseSamplingTile (Sampling.cpp:427-466): tiles of 40/sqrt(spp) output pixels at accumulated positions,
