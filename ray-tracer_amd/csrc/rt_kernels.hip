@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
                 const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
                 keep = scene_may_hit(S, lds, r, RT_INFINITY);
             }
-            if (!keep) {
+            if (!keep && !(masked && g.mask_skips_rgb)) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
                 if (out_spec) for (int i = 0; i < RT_NSPEC; i++) out_spec[(size_t)k * RT_NSPEC + i] = 0.0f;
             }
@@ -893,7 +893,10 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
             if (ly < -1 || ly > RT_BLUE_NSQRT) continue;
             int cell = (ly + 1) * (RT_BLUE_NSQRT + 2) + (lx + 1);
             int e0 = T.offsets[cell], e1 = T.offsets[cell + 1];
-            int64_t sbase = ((int64_t)tx * g.tiles_y_local + (ty - g.tile_y0)) * RT_BLUE_N;
+            const int tile = tx * g.tiles_y_local + (ty - g.tile_y0);
+            int64_t sbase = (int64_t)tile * RT_BLUE_N;
+            /* a masked tile's samples are black: they add weight only (adding +0 to a sum that is never -0 changes nothing) */
+            const bool black = g.tile_mask && g.mask_skips_rgb && g.tile_mask[tile] == 0;
             for (int e = e0; e < e1; e++) {
                 int i = T.entries[e];
                 /* v = g_rgvBlueNoise[i]*BLUE_NSQRT + vTile (Sampling.cpp:501), then FastSplatRGB's own arithmetic */
@@ -905,11 +908,12 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
                 double dx = x - fx, dy = y - fy, wx, wy;
                 if (px == i1) wx = 1.0 - dx; else if (px == i1 + 1) wx = dx; else continue;
                 if (py == j1) wy = 1.0 - dy; else if (py == j1 + 1) wy = dy; else continue;
+                w += (float)(wx * wy);
+                if (black) continue;
                 const float *c = sample_rgb + 3 * (sbase + i);
                 r += (float)((double)(float)((double)c[0] * wx) * wy);
                 gg += (float)((double)(float)((double)c[1] * wx) * wy);
                 b += (float)((double)(float)((double)c[2] * wx) * wy);
-                w += (float)(wx * wy);
             }
         }
     }

@@ -69,6 +69,7 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     /* FASTBLUE: one byte per traced tile (tx * tiles_y_local + local ty), 0 = no ray through the tile can touch a box of
        the scene (k_tile_mask): k_generate_cull finishes its 1600 samples without generating them.  Null = not used. */
     const unsigned char *tile_mask;
+    int     mask_skips_rgb;             /* the caller's reconstruction honours the mask: masked tiles' (black) sample colours are neither written nor read */
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;
