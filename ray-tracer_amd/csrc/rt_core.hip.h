@@ -17,6 +17,7 @@
 
 #define RT_DEV __device__ __forceinline__
 #define RT_DEVN __device__ __noinline__
+#define RT_HD __host__ __device__ inline
 
 struct D3 { double x, y, z; };
 RT_DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -649,7 +650,27 @@ RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
 struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int n_nodes, n_chains, stride; };
 #define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * (L).stride + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
-RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds)
+/* 8-byte words of LDS the small scene tables take when staged (same arithmetic on the host: rt_scene_upload) */
+RT_HD int scene_table_words(const RtDevScene &S)
+{
+    return S.n_prog * (int)(sizeof(RtInstr) / 8) + S.n_boxes * (int)(sizeof(RtBox) / 8) + S.n_affines * (int)(sizeof(RtAffine) / 8) +
+           S.n_mats * (int)(sizeof(RtMaterialDev) / 8) + S.n_surfs * (int)(sizeof(RtSurfaceDev) / 8) + S.n_regions * (int)(sizeof(RtRegion) / 8) +
+           (S.n_child_pc + 1) / 2 + (S.n_lca + 1) / 2;
+}
+template <class T> RT_DEV const T *lds_stage(double *&cur, const T *src, int n)
+{
+    static_assert(sizeof(T) % 4 == 0, "tables are copied as 32-bit words");
+    const int words = n * (int)(sizeof(T) / 4);
+    uint32_t *d = (uint32_t *)cur;
+    const uint32_t *s = (const uint32_t *)src;
+    for (int k = threadIdx.x; k < words; k += blockDim.x) d[k] = s[k];
+    cur += (words + 1) / 2;
+    return (const T *)d;
+}
+/* SL (optional): a copy of the scene description whose small tables -- program, boxes, affines, materials, surfaces,
+   regions and their child / LCA tables -- point at LDS copies.  Their lookups are per-lane gathers (every lane is at
+   its own instruction, material, box ...): in LDS they cost bank cycles, through the vector L1 one cache line each. */
+RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds, RtDevScene *SL = 0)
 {
     extern __shared__ double rt_dyn_lds[];
     SceneLds L;
@@ -662,7 +683,18 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds)
     for (int k = threadIdx.x; k < words_ch; k += blockDim.x) rt_dyn_lds[words_bvh + k] = src2[k];
     L.bvh = rt_dyn_lds;
     L.chains = (const RtChain *)(rt_dyn_lds + words_bvh);
-    L.stack = (uint16_t *)(rt_dyn_lds + words_bvh + words_ch);
+    double *cur = rt_dyn_lds + words_bvh + words_ch;
+    if (SL) {
+        SL->prog = lds_stage(cur, S.prog, S.n_prog);
+        SL->boxes = lds_stage(cur, S.boxes, S.n_boxes);
+        SL->affines = lds_stage(cur, S.affines, S.n_affines);
+        SL->mats = lds_stage(cur, S.mats, S.n_mats);
+        SL->surfs = lds_stage(cur, S.surfs, S.n_surfs);
+        SL->regions = lds_stage(cur, S.regions, S.n_regions);
+        SL->region_child_pc = lds_stage(cur, S.region_child_pc, S.n_child_pc);
+        SL->region_lca = lds_stage(cur, S.region_lca, S.n_lca);
+    }
+    L.stack = (uint16_t *)cur;
     __syncthreads();
     return L;
 }

@@ -187,6 +187,7 @@ typedef struct RtDevScene {
     const float         *metal_nk;      /* [11][2][10]: refraction, extinction per MAT_* */
     int32_t n_prog, n_lights, has_ambient, sampler, venera, n_bvh;
     int32_t n_bvh_lds, n_chains;        /* BVH nodes staged in LDS; number of chain records */
+    int32_t n_boxes, n_affines, n_mats, n_surfs, n_regions, n_child_pc, n_lca;      /* table sizes, for staging them in LDS */
     int32_t aux_light, aux_tex;         /* which per-sample auxiliary dimensions outlive sample generation: g_u/vLight (an area light
                                            exists), g_u/vMicroFacet (a texture call-out exists); g_u/vCamera never does */
     int32_t root_cull, root_cull_arg;   /* 0: none; 1: the whole program is union region root_cull_arg; 2: ... is one chain with box root_cull_arg */

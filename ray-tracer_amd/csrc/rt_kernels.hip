@@ -372,11 +372,15 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
  * LITE = true is the common kernel: a ray that meets a torus, a textured hit, a propagating medium or a spectral
  * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
-template <bool LITE, bool CH_LDS>
+/* MODE: what the workgroup stages in LDS besides the top of the BVH -- 0 nothing, 1 the chain records, 2 the chain records
+   and the small scene tables (scene_lds_load); chosen per scene at upload, compiled in so that the loads are LDS loads */
+template <bool LITE, int MODE>
 __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
-    const RtDevScene &S = Sv;
-    const SceneLds lds = scene_lds_load(S, n_chains_lds);
+    constexpr bool CH_LDS = MODE >= 1;
+    RtDevScene SL = Sv;
+    const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
+    const RtDevScene &S = SL;
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
     const int n = LITE ? (f1 - f0) : P.counters[CTR_SLOW_V];
@@ -553,11 +557,13 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
 
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
-template <bool LITE, bool CH_LDS>
+template <bool LITE, int MODE>
 __global__ void __launch_bounds__(LITE ? RT_LITE_SHADOW_THREADS : 256) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
-    const RtDevScene &S = Sv;
-    const SceneLds lds = scene_lds_load(S, n_chains_lds);
+    constexpr bool CH_LDS = MODE >= 1;
+    RtDevScene SL = Sv;
+    const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
+    const RtDevScene &S = SL;
     const int n = LITE ? nrays : P.counters[CTR_SLOW_S];
     int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
     const int wlane = threadIdx.x & 63;
