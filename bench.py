@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 # algorithmic work of the dominant kernel (k_visual), SURVEY.md section 8d weights, flops per event
 W_AFFINE, W_QUADRIC, W_BOX, W_MERGE, W_SHADE, W_SHADE_LIGHT = 33.0, 57.0, 30.0, 6.0, 250.0, 60.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = half of the 157.3 TF FP32 vector peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
+# PMC measurement of the same workload (a copy of profiles/r01_f_pmc_traffic_k_visual.json kept where GPU runs can read it)
+TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic_k_visual.json")
 
 
 def main():
@@ -127,7 +130,7 @@ def main():
                        "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows},
             "sec_per_frame": dt / args.steps,
         }
-        res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace)
+        res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene)
         print(json.dumps(res))
@@ -135,12 +138,15 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total):
-    """Dominant kernel = k_visual (intersection + boundary shading of every visual ray).  achieved =
-    algorithmic flops per launch / average launch duration, both measured here: the kernel is timed with
-    HIP events on its own stream by re-running one chunk through the parity probe path, and the flops are
-    SURVEY 8d's per-event weights times the IDEAL-culling event counts (leaf tests = leaves whose own box
-    the ray touches), counted by the device on a sample of the workload's own camera rays."""
+def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total, workload):
+    """Dominant kernel = k_visual (intersection + boundary shading of every visual ray).  Its nearest hard roof is HBM:
+    a wavefront kernel streams one frame record per ray.  achieved = ALGORITHMIC bytes per launch / average launch
+    duration: per ray 56 B read (ray, flags, root) + 16 B per auxiliary pair the scene needs (area light -> 1) + 4 B
+    flags written, + 144 B (geometry 128 + ids 16) per shaded boundary, + 56 B per shadow ray queued (DESIGN.md section
+    6); the duration is measured with HIP events on the kernel's own stream (option time_kernels).  traffic = HBM bytes
+    per launch from PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), when this is the
+    workload they were collected on.  The FP64-vector view of the same launches (SURVEY 8d's per-event flop weights x
+    IDEAL-culling event counts, counted by the device on a sample of the workload's camera rays) is in "valu_fp64"."""
     _, _, total = gs.samples(W, H, spp, 0, 0)
     ntile = total // 1600
     picks = sorted(set(int(x) for x in np.linspace(0, ntile - 1, 64)))
@@ -152,21 +158,34 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total):
     L.rt_probe_work.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     rc = L.rt_probe_work(gs.h, m, org.ctypes.data_as(C.POINTER(C.c_double)), dr.ctypes.data_as(C.POINTER(C.c_double)), work.ctypes.data_as(C.POINTER(C.c_double)))
     if rc:
-        return {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "note": "rt_probe_work failed: %s" % L.rt_last_error().decode()}
     leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch, m_reach = work
     if m_reach <= 0 or ms_per_launch <= 0:
-        return {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "note": "no ray reached k_visual"}
     frac_reach = m_reach / m
     m = m_reach         # per-ray figures are over the rays k_visual processes
     per_ray = (leaf * (W_AFFINE + W_QUADRIC) + boxes_ideal * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
     flops = per_ray * rays_per_launch
     ach = flops / (ms_per_launch * 1e-3) / 1e12
-    return {"bound": "valu_fp64", "kernel": "k_visual", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-            "flops_per_ray": per_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch,
+    d = fs.desc.contents
+    area = any(d.lights[i].type == rt.RT_LIGHT_AREA for i in range(d.n_lights))
+    visual_rays = max(1, st.rays_primary + st.rays_secondary)
+    bytes_per_ray = 56.0 + (16.0 if area else 0.0) + 4.0 + 144.0 * boundaries / m + 56.0 * st.rays_shadow / visual_rays
+    gbs = bytes_per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(TRAFFIC_FILE) as f:
+            tf = json.load(f)
+        if workload.startswith(tf["workload"]):
+            traffic = tf["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"bound": "hbm", "kernel": "k_visual", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch,
             "rays_reaching_kernel": frac_reach,
+            "valu_fp64": {"achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "flops_per_ray": per_ray},
             "events_per_ray": {"leaf_tests": leaf / m, "ideal_box_tests": boxes_ideal / m, "merged_hits": merged / m,
                                "shaded_boundaries": boundaries / m, "light_terms": lights / m}}
 

@@ -20,6 +20,9 @@ class RtNode(C.Structure):
                 ("data", C.c_int32), ("ndata", C.c_int32)]
 
 
+RT_LIGHT_POINT, RT_LIGHT_AREA = 0, 1      # enum RtLightType, include/rt_scene_desc.h
+
+
 class RtLight(C.Structure):
     _fields_ = [("type", C.c_int32), ("no_shadow", C.c_int32), ("org", C.c_double * 3),
                 ("vA", C.c_double * 3), ("vB", C.c_double * 3), ("flux", C.c_float * NSPEC)]
