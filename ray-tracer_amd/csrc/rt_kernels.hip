@@ -362,11 +362,24 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 
 /* workgroup sizes of the common (LITE) kernels: one workgroup per CU, 3 resp. 4 waves per SIMD, which also bounds
    their VGPRs (512 / waves per SIMD) */
+#ifdef RT_SMALL_BLOCKS      /* A/B variant: 256-thread workgroups, several per CU, the same waves per SIMD */
+#define RT_LITE_VISUAL_THREADS 256
+#define RT_LITE_SHADOW_THREADS 256
+#define RT_LITE_VISUAL_PER_CU  3
+#define RT_LITE_SHADOW_PER_CU  4
+#define RT_LB_VISUAL(LITE) __launch_bounds__(256, (LITE) ? 3 : 1)
+#define RT_LB_SHADOW(LITE) __launch_bounds__(256, (LITE) ? 4 : 1)
+#else
 #ifndef RT_LITE_VISUAL_THREADS
 #define RT_LITE_VISUAL_THREADS 768
 #endif
 #ifndef RT_LITE_SHADOW_THREADS
 #define RT_LITE_SHADOW_THREADS 1024
+#endif
+#define RT_LITE_VISUAL_PER_CU  1
+#define RT_LITE_SHADOW_PER_CU  1
+#define RT_LB_VISUAL(LITE) __launch_bounds__((LITE) ? RT_LITE_VISUAL_THREADS : 256)
+#define RT_LB_SHADOW(LITE) __launch_bounds__((LITE) ? RT_LITE_SHADOW_THREADS : 256)
 #endif
 /* ------------------------------------------------------------------ k_visual
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
@@ -375,7 +388,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 /* MODE: what the workgroup stages in LDS besides the top of the BVH -- 0 nothing, 1 the chain records, 2 the chain records
    and the small scene tables (scene_lds_load); chosen per scene at upload, compiled in so that the loads are LDS loads */
 template <bool LITE, int MODE>
-__global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
+__global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(LITE ? RT_LITE_VISUAL_THREADS : 256) k_visual(
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
 template <bool LITE, int MODE>
-__global__ void __launch_bounds__(LITE ? RT_LITE_SHADOW_THREADS : 256) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
+__global__ void RT_LB_SHADOW(LITE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;
@@ -880,14 +893,10 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
  * pixel GATHERS its (on average four) contributions in the reference's loop order -- tile x outer, tile y
  * inner, sample index, corner -- from a per-tile-pixel contributor table built once from the blue-noise
  * tile, which reproduces the reference's float accumulation bit for bit and needs no atomics. */
-__global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
-                                                      int y0, int y1, float *im2 /*[3][rows][nW]*/, float *wt2 /*[rows][nW]*/)
+RT_DEV void splat_pixel(const RtDevScene &S, const RtSampleGrid &g, const RtSplatTable &T, const float *sample_rgb, int px, int py,
+                        float &r, float &gg, float &b, float &w)
 {
-    const RtDevScene &S = Sv;
-    int px = blockIdx.x * blockDim.x + threadIdx.x;
-    int py = y0 + blockIdx.y;
-    if (px >= g.nW || py >= y1) return;
-    float r = 0.0f, gg = 0.0f, b = 0.0f, w = 0.0f;
+    r = 0.0f; gg = 0.0f; b = 0.0f; w = 0.0f;
     int tcx = px / RT_BLUE_NSQRT, tcy = py / RT_BLUE_NSQRT;
     for (int tx = tcx - 1; tx <= tcx + 1; tx++) {
         if (tx < 0 || tx >= g.tiles_x) continue;
@@ -923,6 +932,15 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
             }
         }
     }
+}
+__global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSampleGrid g, RtSplatTable T, const float *sample_rgb,
+                                                      int y0, int y1, float *im2 /*[3][rows][nW]*/, float *wt2 /*[rows][nW]*/)
+{
+    int px = blockIdx.x * blockDim.x + threadIdx.x;
+    int py = y0 + blockIdx.y;
+    if (px >= g.nW || py >= y1) return;
+    float r, gg, b, w;
+    splat_pixel(Sv, g, T, sample_rgb, px, py, r, gg, b, w);
     size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
     im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b;
     wt2[o] = w;
@@ -1199,6 +1217,53 @@ __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int pla
     }
     if (wsum != 0.0) sum /= wsum;
     dst[((size_t)pl * rows + row) * n_dst + id] = (float)sum;
+}
+
+/* Splat gather and the horizontal resampling pass in one kernel: a workgroup produces the supersample pixels that 128
+   output pixels of one supersample row read (their span plus the filter's reach), keeps the four planes in LDS and
+   filters them from there -- the supersampled image (8.5 GB at 4K / 64 spp, written once and read once) never exists.
+   Same gather (splat_pixel), same taps, same summation order as k_splat_gather + k_resample_rows. */
+#define RT_FS_DST   128
+#define RT_FS_SPAN  1152        /* source pixels per workgroup: 128 * ratio + taps, ratio <= 8.5 */
+__global__ void __launch_bounds__(256) k_splat_resample_rows(const RtDevScene Sv, RtSampleGrid g, RtSplatTable ST, const float *sample_rgb,
+                                                             int y0, int y1, int n_dst, RtTapTable T, float *dst3 /*[3][rows][n_dst]*/, float *dstw /*[rows][n_dst]*/)
+{
+    __shared__ float  s_px[4][RT_FS_SPAN + RT_FS_SPAN / 32 + 2];
+    __shared__ double s_taps[RT_RS_TAPS];
+    const int id0 = blockIdx.x * RT_FS_DST, row = blockIdx.y, py = y0 + row, n_src = g.nW;
+    const int last = (id0 + RT_FS_DST - 1 < n_dst ? id0 + RT_FS_DST - 1 : n_dst - 1);
+    const int base = T.first[id0], span = T.first[last] + T.count[last] - base;      /* host: 0 < span <= RT_FS_SPAN */
+    const bool utaps = T.uniform && T.max_count <= RT_RS_TAPS;
+    for (int j = threadIdx.x; j < span; j += 256) {
+        int is = base + j, px = is;
+        if ((unsigned)is >= (unsigned)n_src) px = is < 0 ? 0 : n_src - 1;           /* WRAP_CLAMP */
+        float r, gg, b, w;
+        splat_pixel(Sv, g, ST, sample_rgb, px, py, r, gg, b, w);
+        const int q = RT_RS_IDX(j);
+        s_px[0][q] = r; s_px[1][q] = gg; s_px[2][q] = b; s_px[3][q] = w;
+    }
+    if (utaps) {
+        const double *p0 = T.taps + T.offset[0];
+        for (int k = threadIdx.x; k < T.max_count; k += 256) s_taps[k] = p0[k];
+    }
+    __syncthreads();
+    const int id = id0 + (threadIdx.x & (RT_FS_DST - 1)), half = threadIdx.x >> 7;      /* planes 2 * half, 2 * half + 1 */
+    if (id >= n_dst) return;
+    const int j0 = T.first[id] - base, cnt = T.count[id];
+    const double *pf = T.taps + T.offset[id];
+    double sum0 = 0.0, sum1 = 0.0, wsum = 0.0;
+    const float *a0 = s_px[2 * half], *a1 = s_px[2 * half + 1];
+    for (int k = 0; k < cnt; k++) {
+        const double fw = utaps ? s_taps[k] : pf[k];
+        const int q = RT_RS_IDX(j0 + k);
+        sum0 += fw * (double)a0[q];
+        sum1 += fw * (double)a1[q];
+        wsum += fw;
+    }
+    if (wsum != 0.0) { sum0 /= wsum; sum1 /= wsum; }
+    const size_t rows = (size_t)(y1 - y0), o = (size_t)row * n_dst + id;
+    if (half == 0) { dst3[o] = (float)sum0; dst3[rows * n_dst + o] = (float)sum1; }
+    else { dst3[2 * rows * n_dst + o] = (float)sum0; dstw[o] = (float)sum1; }
 }
 
 /* vertical pass: src [planes][src_rows_local][width] (rows src_y0..), dst rows [row0,row1) of [planes][H][width] */

@@ -332,6 +332,24 @@ def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
     assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
 
 
+def test_fused_splat_and_row_filter_equals_two_kernels(gpu):
+    """k_splat_resample_rows (gather + horizontal filter through LDS, no supersampled image in memory) gives the bits of
+    k_splat_gather + k_resample_rows: integer and fractional decimation ratios, upsampling, bands, widths that are not a
+    multiple of the workgroup's 128 destinations."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene("S1", "fastblue", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    try:
+        for (w, h, spp, r0, r1) in ((130, 75, 4, 0, 0), (64, 64, 1.5, 20, 41), (333, 17, 2, 0, 0), (50, 300, 9, 100, 130), (300, 40, 64, 0, 0), (97, 31, 0.5, 0, 0)):
+            L.rt_set_option(b"fuse_splat", 1)
+            a, _ = g.render(w, h, spp, row0=r0, row1=r1)
+            L.rt_set_option(b"fuse_splat", 0)
+            b, _ = g.render(w, h, spp, row0=r0, row1=r1)
+            assert np.array_equal(a, b), (w, h, spp)
+    finally:
+        L.rt_set_option(b"fuse_splat", 0)
+
+
 @pytest.mark.parametrize("scene", ["S0", "S1", SCENE_ROW, SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC])
 def test_tile_mask_is_invisible(gpu, scene):
     """The tile mask (a cone-against-bounding-sphere test per sampling tile that lets whole tiles end before their samples
