@@ -54,7 +54,10 @@ enum RtTextureId {
     RT_TEX_NONE = 0, RT_TEX_BUMPY = 1, RT_TEX_MICROFACETS = 2, RT_TEX_MICROFACETS2 = 3, RT_TEX_WRINKLED = 4,
     RT_TEX_FACETED20 = 5, RT_TEX_DENTED = 6, RT_TEX_WAVY = 7, RT_TEX_FIBERS = 8, RT_TEX_BLISTERED = 9,
     RT_TEX_HAMMERED = 10, RT_TEX_TECTONIC = 11, RT_TEX_QUASIMICROFACET = 12, RT_TEX_VORONOIBUMP = 13,
-    RT_TEX_VORONOIANTIBUMP = 14, RT_TEX_VORONOICRINKLED = 15, RT_TEX__COUNT
+    RT_TEX_VORONOIANTIBUMP = 14, RT_TEX_VORONOICRINKLED = 15,
+    /* solid colour textures (TextureMaps.cpp:518-700) and SeaScape (:497-513, which has no effect on the hit) */
+    RT_TEX_VORONOI = 16, RT_TEX_AGATE = 17, RT_TEX_MARBLE = 18, RT_TEX_CLOUDS = 19, RT_TEX_WOOD = 20, RT_TEX_SPOTS = 21,
+    RT_TEX_VEINS = 22, RT_TEX_SEASCAPE = 23, RT_TEX__COUNT
 };
 /* Propagator function pointers (Solids.h:267); 0 = none. */
 enum RtPropagatorId { RT_PROP_NONE = 0, RT_PROP_COLOREDGLASS = 1, RT_PROP_FOGGY = 2, RT_PROP__COUNT };

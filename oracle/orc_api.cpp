@@ -71,6 +71,8 @@ extern "C" int orc_load_tables(const char *path)
     if (!find_table(blob, "g_rgvBlueNoise", dt, cnt, off) || dt != 1 || cnt != 2 * RT_BLUE_N) return -5;
     g_t.blue.resize(cnt);
     memcpy(&g_t.blue[0], &blob[off], sizeof(double) * cnt);
+    if (!load_spec(blob, "g_sGreen", g_t.s_green) || !load_spec(blob, "g_sEqualWhite", g_t.s_white) || !load_spec(blob, "g_sOrange", g_t.s_orange) ||
+        !load_spec(blob, "g_sRed", g_t.s_red) || !load_spec(blob, "g_sBlue", g_t.s_blue)) return -7;
     if (!find_table(blob, "DiskSamples128", dt, cnt, off) || dt != 1 || cnt != 256) return -6;
     g_t.disk128.resize(cnt);
     memcpy(&g_t.disk128[0], &blob[off], sizeof(double) * cnt);

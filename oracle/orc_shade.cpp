@@ -335,6 +335,7 @@ Spec visual_ray(Scene &s, const Ray &ray, Ctx &cx)
     if (cx.depth >= 11)
         return black;
     HitList hl;
+    if (cx.depth == 0) cx.drop_scratch();
     if (cx.depth == 0) cx.n_primary++; else cx.n_secondary++;
     node_hits(s.root, ray, cx, hl);
     cx.depth++;

@@ -36,6 +36,7 @@ struct Tables {
     Spec  chan[3];                      /* g_sRedChannel, g_sGrnChannel, g_sBluChannel */
     std::vector<double> blue;           /* g_rgvBlueNoise, 1600 x 2 */
     std::vector<double> disk128;        /* DiskSamples128, 128 x 2 (LowDiscrepancy.cpp:129) */
+    Spec  s_green, s_white, s_orange, s_red, s_blue;  /* g_sGreen, g_sEqualWhite, g_sOrange, g_sRed, g_sBlue: the solid colour textures' palette */
     Tables() : loaded(false) {}
 };
 extern Tables g_t;

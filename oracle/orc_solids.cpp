@@ -598,3 +598,18 @@ Node *optimize(Node *n, Node *enclosing)
 }
 
 } // namespace orc
+
+namespace orc {
+/* Q13 (orc_solids.h): private material copies for hits whose colour / luster a solid texture sets */
+Node *Ctx::clone_material(const Node *m) const
+{
+    Node *c = new Node(*m);
+    scratch.push_back(c);
+    return c;
+}
+void Ctx::drop_scratch() const
+{
+    for (size_t i = 0; i < scratch.size(); i++) delete scratch[i];
+    scratch.clear();
+}
+} // namespace orc

@@ -38,6 +38,9 @@ struct Hit {                    /* RayTracer2020.h:108-132 */
     Node   *leaf;               /* instrumentation: primitive that produced the root */
     std::vector<TexRef> tex;
 };
+/* Q13: the solid colour textures write pm->color / pm->nLuster of the SHARED Material (TextureMaps.cpp:530-683).  Stated
+   policy, as for the spectral metals (Q3): the write goes to a private copy of the material that this one hit refers to
+   from then on, so a hit is coloured by the texture value at its own position and nothing leaks to other rays. */
 typedef std::vector<Hit> HitList;
 
 struct Extent { V3 lo, hi; };
@@ -47,6 +50,10 @@ struct Ctx {                    /* the reference's file-static / global state, m
     int    depth;               /* static nRayDepth, Shade.cpp:416 */
     double aux[6];              /* g_uCamera,g_vCamera,g_uLight,g_vLight,g_uMicroFacet,g_vMicroFacet */
     long   n_primary, n_shadow, n_secondary;
+    mutable std::vector<Node *> scratch;    /* per-hit material copies made by colour textures (Q13); emptied per primary ray */
+    Node  *clone_material(const Node *m) const;
+    void   drop_scratch() const;
+    ~Ctx() { drop_scratch(); }
     Ctx() : last_affine(0), depth(0), n_primary(0), n_shadow(0), n_secondary(0) { for (int i = 0; i < 6; i++) aux[i] = 0.0; }
 };
 

@@ -171,6 +171,96 @@ float gradient_voronoi(float *grad, const float *p, int npow)
     return float(f);
 }
 
+/* FractalNoise, Texture.cpp:200-241, as the solid textures call it: fractal dimension 1, lacunarity 1.9, a whole number
+   of levels (the remainder branch never runs) */
+static float fractal_noise(const float *p, int ndim, int levels, int absolute)
+{
+    const float lac = 1.9f, omega = powf(lac, -1.0f);
+    float wl = 1.0f, noise = 0.0f, gain = 0.0f, sc[3] = { 0.0f, 0.0f, 0.0f };
+    for (int j = 0; j < ndim; j++) sc[j] = p[j];
+    for (int i = 0; i < levels; i++) {
+        float fb = wl * (band_noise(sc, ndim) - 0.5f);
+        if (absolute) fb = fabsf(fb);
+        noise += fb;
+        gain += wl;
+        wl *= omega;
+        for (int j = 0; j < ndim; j++) sc[j] *= lac;
+    }
+    return noise / gain + 0.5f;
+}
+static double sawtooth_wave(double x)                   /* TextureMaps.cpp:546-555 */
+{
+    x = (0.5 / kPi) * x + 0.25;
+    x = 2.0 * (x - floor(x));
+    if (x < 1.0) return 2.0 * x - 1.0;
+    return 3.0 - 2.0 * x;
+}
+static double wood_wave(double x)                       /* TextureMaps.cpp:590-604 */
+{
+    x = (0.5 / kPi) * x + 0.25;
+    x = 2.0 * (x - floor(x));
+    if (x < 1.0) return 0.0;
+    else if (x < 1.5) { x = 2.0 * (x - 1.0); return 0.5 * x * x; }
+    else { x = 2.0 * (x - 2.0); return -0.5 * x * x + 1.0; }
+}
+/* the solid colour textures, TextureMaps.cpp:518-683: colour (and for Spots the luster) of the material this hit enters;
+   written to a private copy of the material (Q13, orc_solids.h) */
+static void colour_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
+{
+    const double sc = tex == RT_TEX_WOOD ? 3.0 : 7.0;
+    float q[3] = { float(p.x * sc), float(p.y * sc), float(p.z * sc) };
+    Node *m = cx.clone_material(h.mat);
+    h.mat = m;
+    switch (tex) {
+    case RT_TEX_VORONOI: {
+        float g[3];
+        double fBlend = gradient_voronoi(g, q, 1) / 1.6;        /* Voronoi(rgf): the same search, value only (Texture.cpp:334-378) */
+        if (fBlend > 1.0) fBlend = 1.0;
+        m->color = g_t.s_green * fBlend + g_t.s_white * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_AGATE: {
+        double fBlend = band_noise(q, 3);
+        fBlend = 0.5 * (sin(100.0 * fBlend) + 1.0);
+        m->color = g_t.s_orange * fBlend + g_t.s_white * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_MARBLE: {
+        Spec pink = g_t.s_white * 0.67 + g_t.s_red * 0.33;
+        double d = sawtooth_wave(q[2] + 12.0 * fractal_noise(q, 3, 5, 1));
+        d = d * d;
+        m->color = pink * (1.0 - d);
+        return;
+    }
+    case RT_TEX_CLOUDS: {
+        double fBlend = 2.0 * fractal_noise(q, 3, 5, 0) - 1.0;
+        if (fBlend < 0.0) fBlend = 0.0; else if (fBlend > 1.0) fBlend = 1.0;
+        m->color = g_t.s_white * fBlend + g_t.s_blue * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_WOOD: {
+        double fWarp = 3.0f * fractal_noise(q, 3, 2, 0);
+        q[0] += float(fWarp);
+        double fBlend = 0.5 + 0.5 * wood_wave(50.0 * sqrt(q[0] * q[0] + q[1] * q[1]));
+        fBlend = 0.9 * fBlend + 0.1 * sawtooth_wave(250.0 * (1.0 + fBlend) * sqrt(q[0] * q[0] + q[1] * q[1]));
+        fBlend = 1.0 - fBlend;
+        m->color = (g_t.s_orange + g_t.s_red) * (0.25 * fBlend) + g_t.s_white * 0.03;
+        return;
+    }
+    case RT_TEX_SPOTS: {
+        double fBlend = band_noise(q, 3);
+        if (fBlend > 0.5) m->i0 = RT_MAT_COPPER;
+        else { m->i0 = RT_MAT_PLASTIC; m->color = spec_const(0.0f); }
+        return;
+    }
+    case RT_TEX_VEINS: {
+        double fBlend = fractal_noise(q, 3, 5, 0) - 0.5;
+        if (fabs(fBlend) > 0.02) m->color = g_t.s_green * 0.125; else m->color = g_t.s_white;
+        return;
+    }
+    }
+}
+
 /* TextureMaps.cpp:189-198 */
 static void perturb(Hit &h, const V3 &d)
 {
@@ -194,6 +284,9 @@ extern const V3 kDodecahedronNormals[20];
 void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
 {
     switch (tex) {
+    case RT_TEX_VORONOI: case RT_TEX_AGATE: case RT_TEX_MARBLE: case RT_TEX_CLOUDS: case RT_TEX_WOOD: case RT_TEX_SPOTS: case RT_TEX_VEINS:
+        colour_texture(tex, p, h, cx); return;
+    case RT_TEX_SEASCAPE:     return;       /* TextureMaps.cpp:497-513: the loop computes points and discards them */
     case RT_TEX_BUMPY:        bump3(p, h, 50.0); return;
     case RT_TEX_MICROFACETS:  bump3(p, h, 500.0); return;
     case RT_TEX_MICROFACETS2: bump3(p, h, 5000.0); return;

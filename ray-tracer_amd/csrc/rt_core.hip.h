@@ -1107,6 +1107,10 @@ struct ShadeHit {           /* a hit as the shader sees it after TransformNormal
     D3 n, np;
     int perturbed;
     int surf, mat;
+    /* Q13: a solid colour texture sets the colour (Spots: the luster) of the material this hit enters; the reference
+       writes them into the shared Material, here they belong to the hit (the oracle does the same) */
+    int has_color, luster_ov;       /* luster_ov < 0: the material's own */
+    Spec color;
 };
 
 RT_DEV void perturb(ShadeHit &h, const D3 &d)      /* PerturbNormal, TextureMaps.cpp:189-198 */
@@ -1195,9 +1199,107 @@ __device__ float gradient_fractal_noise(float *grad, const float *p, int ndim, i
     return noise * gain + 0.5f;
 }
 
-RT_DEVN void apply_texture(int tex, const D3 &p, ShadeHit &h, const double *aux, float omega)        /* TextureMaps.cpp:209-369 */
+/* BandNoise (Texture.cpp:98-123, nPow == 1, three dimensions): the value-only spline over its own lattice seed */
+RT_DEV float band_noise3(const float *p)
+{
+    NoiseSetup s;
+    noise_setup(s, p, 3);
+    float g0, g1, g2;
+    const float v = gspline3(s, 1099087573u, &g0, &g1, &g2);       /* Spline(nDim, 1099087573): the same knots and coefficients */
+    return s.gain * v * (0.9f / 4294967296.0f) + 0.5f;
+}
+/* FractalNoise, Texture.cpp:200-241: fractal dimension 1, lacunarity 1.9, whole levels */
+RT_DEV float fractal_noise3(const float *p, int levels, int absolute, float omega19)
+{
+    const float lac = 1.9f;
+    float wl = 1.0f, noise = 0.0f, gain = 0.0f, sc[3] = { p[0], p[1], p[2] };
+    for (int i = 0; i < levels; i++) {
+        float fb = wl * (band_noise3(sc) - 0.5f);
+        if (absolute) fb = fabsf(fb);
+        noise += fb;
+        gain += wl;
+        wl *= omega19;
+        for (int j = 0; j < 3; j++) sc[j] *= lac;
+    }
+    return noise / gain + 0.5f;
+}
+RT_DEV double sawtooth_wave(double x)                    /* TextureMaps.cpp:546-555 */
+{
+    x = (0.5 / RT_PI) * x + 0.25;
+    x = 2.0 * (x - floor(x));
+    if (x < 1.0) return 2.0 * x - 1.0;
+    return 3.0 - 2.0 * x;
+}
+RT_DEV double wood_wave(double x)                        /* TextureMaps.cpp:590-604 */
+{
+    x = (0.5 / RT_PI) * x + 0.25;
+    x = 2.0 * (x - floor(x));
+    if (x < 1.0) return 0.0;
+    else if (x < 1.5) { x = 2.0 * (x - 1.0); return 0.5 * x * x; }
+    else { x = 2.0 * (x - 2.0); return -0.5 * x * x + 1.0; }
+}
+/* solid colour textures, TextureMaps.cpp:518-683 (Q13: the colour belongs to the hit) */
+RT_DEVN void colour_texture(const RtDevScene &S, int tex, const D3 &p, ShadeHit &h)
+{
+    const double sc = tex == RT_TEX_WOOD ? 3.0 : 7.0;
+    float q[3] = { (float)(p.x * sc), (float)(p.y * sc), (float)(p.z * sc) };
+    const Spec green = spec_load(S.tex_palette[0]), white = spec_load(S.tex_palette[1]), orange = spec_load(S.tex_palette[2]),
+               red = spec_load(S.tex_palette[3]), blue = spec_load(S.tex_palette[4]);
+    h.has_color = 1;
+    switch (tex) {
+    case RT_TEX_VORONOI: {
+        float g[3];
+        double fBlend = gradient_voronoi(g, q, 1) / 1.6;
+        if (fBlend > 1.0) fBlend = 1.0;
+        h.color = green * fBlend + white * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_AGATE: {
+        double fBlend = band_noise3(q);
+        fBlend = 0.5 * (sin(100.0 * fBlend) + 1.0);
+        h.color = orange * fBlend + white * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_MARBLE: {
+        const Spec pink = white * 0.67 + red * 0.33;
+        double d = sawtooth_wave(q[2] + 12.0 * fractal_noise3(q, 5, 1, S.fractal_omega19));
+        d = d * d;
+        h.color = pink * (1.0 - d);
+        return;
+    }
+    case RT_TEX_CLOUDS: {
+        double fBlend = 2.0 * fractal_noise3(q, 5, 0, S.fractal_omega19) - 1.0;
+        if (fBlend < 0.0) fBlend = 0.0; else if (fBlend > 1.0) fBlend = 1.0;
+        h.color = white * fBlend + blue * (1.0 - fBlend);
+        return;
+    }
+    case RT_TEX_WOOD: {
+        const double fWarp = 3.0f * fractal_noise3(q, 2, 0, S.fractal_omega19);
+        q[0] += (float)fWarp;
+        double fBlend = 0.5 + 0.5 * wood_wave(50.0 * sqrt(q[0] * q[0] + q[1] * q[1]));
+        fBlend = 0.9 * fBlend + 0.1 * sawtooth_wave(250.0 * (1.0 + fBlend) * sqrt(q[0] * q[0] + q[1] * q[1]));
+        fBlend = 1.0 - fBlend;
+        h.color = (orange + red) * (0.25 * fBlend) + white * 0.03;
+        return;
+    }
+    case RT_TEX_SPOTS: {
+        const double fBlend = band_noise3(q);
+        if (fBlend > 0.5) { h.luster_ov = RT_MAT_COPPER; h.has_color = 0; }
+        else { h.luster_ov = RT_MAT_PLASTIC; h.color = spec_const(0.0f); }
+        return;
+    }
+    default: {      /* RT_TEX_VEINS */
+        const double fBlend = fractal_noise3(q, 5, 0, S.fractal_omega19) - 0.5;
+        if (fabs(fBlend) > 0.02) h.color = green * 0.125; else h.color = white;
+        return;
+    }
+    }
+}
+
+RT_DEVN void apply_texture(const RtDevScene &S, int tex, const D3 &p, ShadeHit &h, const double *aux, float omega)        /* TextureMaps.cpp:209-369 */
 {
     float q[3], g[3];
+    if (tex >= RT_TEX_VORONOI && tex <= RT_TEX_VEINS) { colour_texture(S, tex, p, h); return; }
     switch (tex) {
     case RT_TEX_BUMPY: case RT_TEX_MICROFACETS: case RT_TEX_MICROFACETS2: {
         double sc = tex == RT_TEX_BUMPY ? 50.0 : (tex == RT_TEX_MICROFACETS ? 500.0 : 5000.0);
@@ -1307,7 +1409,7 @@ __device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
 template <bool LITE>
 __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail)
 {
-    h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat;
+    h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat; h.has_color = 0; h.luster_ov = -1;
     if constexpr (LITE) {
         if (hr.ntex) { bail = true; return; }
         for (int pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) h.n = covec_mat(h.n, S.affines[pa].minv);
@@ -1319,7 +1421,7 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
         while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == pa) {
             const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
             DRay lr = ray_in_frame(S, wray, tn.tree_affine);
-            apply_texture(tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
+            apply_texture(S, tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
             it++;
         }
         h.n = covec_mat(h.n, S.affines[pa].minv);
@@ -1328,7 +1430,7 @@ __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const H
     while (it < nt && S.texnodes[HIT_TEX(hr, it)].pa == -1) {
         const RtTexNode &tn = S.texnodes[HIT_TEX(hr, it)];
         DRay lr = ray_in_frame(S, wray, tn.tree_affine);
-        apply_texture(tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
+        apply_texture(S, tn.tex, ray_at(lr, hr.t), h, aux, S.fractal_omega);
         it++;
     }
 }

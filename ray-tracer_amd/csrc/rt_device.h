@@ -198,4 +198,6 @@ typedef struct RtDevScene {
     float   chan[3][RT_NSPEC];
     RtCamera cam;
     double  aux_init[6];
+    float   tex_palette[5][RT_NSPEC];   /* g_sGreen, g_sEqualWhite, g_sOrange, g_sRed, g_sBlue: the solid colour textures' spectra */
+    float   fractal_omega19;            /* powf(1.9f, -1.0f) from the host's libm (FractalNoise of the solid textures) */
 } RtDevScene;

@@ -214,7 +214,8 @@ struct Flattener {
     }
     int tex_node(int tex_id, int link_node)
     {
-        static const bool ok[RT_TEX__COUNT] = { true, true, true, true, true, true, true, true, true, true, true, true, true, true, true, true };
+        static const bool ok[RT_TEX__COUNT] = { true, true, true, true, true, true, true, true, true, true, true, true, true, true, true, true,
+                                                true, true, true, true, true, true, true, true };
         if (tex_id <= 0) return -1;
         if (tex_id >= RT_TEX__COUNT || !ok[tex_id]) { fail(RT_ERR_UNSUPPORTED, "texture call-out without a device routine yet (id " + std::to_string(tex_id) + ")"); return -1; }
         RtTexNode t;

@@ -441,13 +441,20 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
         Spec tr = spec_const(1.0f), R = spec_const(0.0f);
         int r_state = 0;                /* 0: R is zero, 1: R is the boundary's ambient term alone, 2: anything else */
         bool tr_one = true;
+        /* Q13: colour / luster a solid texture gave the material the walk is inside of (FULL kernel only: LITE hands
+           textured hits over) */
+        int pm_luster_ov = -1, pm_has_color = 0;
+        Spec pm_color = spec_const(0.0f);
         for (; i < count && !bail; i++) {
             ShadeHit h;
             transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
             if (bail) break;
             const RtMaterialDev &mp = S.mats[pm];
-            if (mp.luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
-                R = spec_load(mp.color);
+            int mp_luster = mp.luster;
+            const float *mp_colorp = mp.color;
+            if constexpr (!LITE) { if (pm_luster_ov >= 0) mp_luster = pm_luster_ov; if (pm_has_color) mp_colorp = pm_color.v; }
+            if (mp_luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
+                R = spec_load(mp_colorp);
                 r_state = 2;
                 flags |= FR_FINAL;
                 break;
@@ -456,23 +463,26 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
                 if constexpr (LITE) { bail = true; break; }
                 else {
                     Spec ptr, pst;
-                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
                     tr = tr * ptr;
                     R = R + pst;
                     r_state = 2; tr_one = false;
                 }
             }
             const RtMaterialDev &mh = S.mats[h.mat];
-            if ((mp.refr != mh.refr) || (mh.luster != RT_MAT_TRANSPARENT)) {
+            int mh_luster = mh.luster;
+            if constexpr (!LITE) if (h.luster_ov >= 0) mh_luster = h.luster_ov;
+            if ((mp.refr != mh.refr) || (mh_luster != RT_MAT_TRANSPARENT)) {
                 D3 vE, cvN;
                 double fNE, F = 0.0, fNT = 0.0;
                 consistent_normal(ray, h, vE, cvN, fNE);
                 Spec color = spec_load(mh.color);
                 bool color_is_mat = true;
-                if (spectral_metal(mh.luster)) {                /* Q3 */
+                if constexpr (!LITE) if (h.has_color) { color = h.color; color_is_mat = false; }
+                if (spectral_metal(mh_luster)) {                /* Q3 */
                     if constexpr (LITE) { bail = true; break; }
                     else {
-                        color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh.luster * 2 * RT_NSPEC + RT_NSPEC);
+                        color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC + RT_NSPEC);
                         F = 1.0;
                         color_is_mat = false;
                     }
@@ -491,7 +501,7 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
                     D3 lo = d3(l.org[0], l.org[1], l.org[2]);
                     if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
                     D3 dir = lo - Ppt;
-                    if (dot(cvN, dir) <= 0.0 && mh.luster != RT_MAT_TRANSPARENT) continue;
+                    if (dot(cvN, dir) <= 0.0 && mh_luster != RT_MAT_TRANSPARENT) continue;
                     if (l.no_shadow) continue;
                     mask |= 1u << li;
                     n_shadow++;
@@ -507,21 +517,23 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
                 P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
                 P.f_geo[(size_t)GEO_ETA * P.fcap + f] = mp.refr / mh.refr;
                 P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
-                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh.luster | ((int)h.mat << 8);
+                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh_luster | ((int)h.mat << 8);
                 if (color_is_mat) flags |= FR_COLOR_MAT; else spec_store(P.f_color, P.fcap, f, color);
                 t = h.t;
                 pm = h.mat;
+                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
                 break;
             } else {
                 t = h.t;
                 pm = h.mat;
+                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
             }
         }
         if (!bail && !(flags & FR_FINAL) && S.mats[pm].prop) {  /* Shade.cpp:512-516 */
             if constexpr (LITE) bail = true;
             else {
                 Spec ptr, pst;
-                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), S.mats[pm].color, ptr, pst);
+                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
                 spec_store(P.f_fin, P.fcap, f, tr * pst);
                 flags |= FR_FIN;
             }
@@ -610,17 +622,26 @@ __global__ void RT_LB_SHADOW(LITE) k_shadow(const RtDevScene Sv, RtPipe P, int n
         double t = 0.0;
         Spec tr = spec_const(1.0f);
         bool blocked = false;
+        int pm_luster_ov = -1, pm_has_color = 0;        /* Q13, as in k_visual */
+        Spec pm_color = spec_const(0.0f);
         for (; !bail && i < count && A.h[start + i].t < 1.0 - RT_EPSILON; i++) {
             ShadeHit h;
             transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
             if (bail) break;
             const RtMaterialDev &mp = S.mats[pm], &mh = S.mats[h.mat];
-            if (mp.luster != RT_MAT_TRANSPARENT || mh.luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
+            int mp_luster = mp.luster, mh_luster = mh.luster;
+            const float *mp_colorp = mp.color;
+            if constexpr (!LITE) {
+                if (pm_luster_ov >= 0) mp_luster = pm_luster_ov;
+                if (pm_has_color) mp_colorp = pm_color.v;
+                if (h.luster_ov >= 0) mh_luster = h.luster_ov;
+            }
+            if (mp_luster != RT_MAT_TRANSPARENT || mh_luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
             if (mp.prop) {
                 if constexpr (LITE) { bail = true; break; }
                 else {
                     Spec ptr, pst;
-                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp.color, ptr, pst);
+                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
                     tr = tr * ptr;
                 }
             }
@@ -634,16 +655,17 @@ __global__ void RT_LB_SHADOW(LITE) k_shadow(const RtDevScene Sv, RtPipe P, int n
             }
             t = h.t;
             pm = h.mat;
+            if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
         }
         if (!bail) {
             Spec out;
             if (blocked) out = spec_const(0.0f);
             else {
-                if (S.mats[pm].prop && S.mats[pm].luster == RT_MAT_TRANSPARENT) {
+                if (S.mats[pm].prop && (pm_luster_ov >= 0 ? pm_luster_ov : S.mats[pm].luster) == RT_MAT_TRANSPARENT) {
                     if constexpr (LITE) bail = true;
                     else {
                         Spec ptr, pst;
-                        propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), S.mats[pm].color, ptr, pst);
+                        propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
                         tr = tr * ptr;
                     }
                 }

@@ -479,6 +479,7 @@ static volatile int s_texfn_tag;
 TEXFN(Bumpy) TEXFN(MicroFacets) TEXFN(MicroFacets2) TEXFN(Wrinkled) TEXFN(Faceted20) TEXFN(Dented) TEXFN(Wavy)
 TEXFN(Fibers) TEXFN(Blistered) TEXFN(Hammered) TEXFN(Tectonic) TEXFN(QuasiMicroFacet)
 TEXFN(VoronoiBump) TEXFN(VoronoiAntiBump) TEXFN(VoronoiCrinkled)
+TEXFN(Voronoi) TEXFN(Agate) TEXFN(Marble) TEXFN(Clouds) TEXFN(Wood) TEXFN(Spots) TEXFN(Veins) TEXFN(SeaScape)
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 int rt_texture_id(TextureMap f)
@@ -488,7 +489,9 @@ int rt_texture_id(TextureMap f)
         { Bumpy, RT_TEX_BUMPY }, { MicroFacets, RT_TEX_MICROFACETS }, { MicroFacets2, RT_TEX_MICROFACETS2 }, { Wrinkled, RT_TEX_WRINKLED },
         { Faceted20, RT_TEX_FACETED20 }, { Dented, RT_TEX_DENTED }, { Wavy, RT_TEX_WAVY }, { Fibers, RT_TEX_FIBERS },
         { Blistered, RT_TEX_BLISTERED }, { Hammered, RT_TEX_HAMMERED }, { Tectonic, RT_TEX_TECTONIC }, { QuasiMicroFacet, RT_TEX_QUASIMICROFACET },
-        { VoronoiBump, RT_TEX_VORONOIBUMP }, { VoronoiAntiBump, RT_TEX_VORONOIANTIBUMP }, { VoronoiCrinkled, RT_TEX_VORONOICRINKLED } };
+        { VoronoiBump, RT_TEX_VORONOIBUMP }, { VoronoiAntiBump, RT_TEX_VORONOIANTIBUMP }, { VoronoiCrinkled, RT_TEX_VORONOICRINKLED },
+        { Voronoi, RT_TEX_VORONOI }, { Agate, RT_TEX_AGATE }, { Marble, RT_TEX_MARBLE }, { Clouds, RT_TEX_CLOUDS }, { Wood, RT_TEX_WOOD },
+        { Spots, RT_TEX_SPOTS }, { Veins, RT_TEX_VEINS }, { SeaScape, RT_TEX_SEASCAPE } };
     for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) if (map[i].f == f) return map[i].id;
     return -1;
 }

@@ -334,6 +334,15 @@ void QuasiMicroFacet(const Point3 &, Hit *, RayTracer *);
 void VoronoiBump(const Point3 &, Hit *, RayTracer *);
 void VoronoiAntiBump(const Point3 &, Hit *, RayTracer *);
 void VoronoiCrinkled(const Point3 &, Hit *, RayTracer *);
+/* solid colour textures (TextureMaps.cpp:518-683) and SeaScape (:497-513) */
+void Voronoi(const Point3 &, Hit *, RayTracer *);
+void Agate(const Point3 &, Hit *, RayTracer *);
+void Marble(const Point3 &, Hit *, RayTracer *);
+void Clouds(const Point3 &, Hit *, RayTracer *);
+void Wood(const Point3 &, Hit *, RayTracer *);
+void Spots(const Point3 &, Hit *, RayTracer *);
+void Veins(const Point3 &, Hit *, RayTracer *);
+void SeaScape(const Point3 &, Hit *, RayTracer *);
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *);
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *);
 int rt_texture_id(TextureMap f);        /* -1: not a device routine */

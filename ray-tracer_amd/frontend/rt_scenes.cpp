@@ -239,7 +239,9 @@ struct Parser {
             { "bumpy", Bumpy }, { "microfacets", MicroFacets }, { "microfacets2", MicroFacets2 }, { "wrinkled", Wrinkled }, { "faceted20", Faceted20 },
             { "dented", Dented }, { "wavy", Wavy }, { "fibers", Fibers }, { "blistered", Blistered }, { "hammered", Hammered },
             { "tectonic", Tectonic }, { "quasimicrofacet", QuasiMicroFacet }, { "voronoibump", VoronoiBump },
-            { "voronoiantibump", VoronoiAntiBump }, { "voronoicrinkled", VoronoiCrinkled } };
+            { "voronoiantibump", VoronoiAntiBump }, { "voronoicrinkled", VoronoiCrinkled },
+            { "voronoi", Voronoi }, { "agate", Agate }, { "marble", Marble }, { "clouds", Clouds }, { "wood", Wood }, { "spots", Spots },
+            { "veins", Veins }, { "seascape", SeaScape } };
         for (size_t i = 0; i < sizeof t / sizeof t[0]; i++) if (w == t[i].n) return t[i].f;
         fail("unknown texture " + w);
         return 0;

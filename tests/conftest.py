@@ -113,6 +113,27 @@ SCENE_FRACTAL = """(scene
  (sampler fastblue))"""
 
 
+# the solid colour textures (TextureMaps.cpp:518-683): every one on a plastic solid; Marble on a metal (colour enters the
+# BRDF and the reflectance); Clouds on coloured glass (the propagator reads the textured colour); Spots on glass (the
+# luster a texture sets decides whether shadow rays pass); SeaScape (no effect) on a surface
+SCENE_COLOUR = """(scene
+ (model (makeunion
+   (translate -3.3 -1.3 0 (surface shiny none (material 0.9 auto g_sWhite plastic voronoi none (sphere))))
+   (translate -1.1 -1.3 0 (surface smooth none (material 0.9 auto g_sWhite plastic agate none (rotate 0.3 0.2 0 (cube)))))
+   (translate 1.1 -1.3 0 (surface polished none (material 0.9 auto g_sWhite metal marble none (sphere))))
+   (translate 3.3 -1.3 0 (surface polished none (material 0.9 1.5 (scale g_sEqualWhite 0.01) transparent clouds coloredglass (sphere))))
+   (translate -3.3 1.1 0 (surface burnished none (material 0.9 auto g_sWhite plastic wood none (cylinder))))
+   (translate -1.1 1.1 0 (surface polished none (material 0.9 1.5 g_sWhite transparent spots none (sphere))))
+   (translate 1.1 1.1 0 (surface shiny seascape (material 0.9 auto g_sWhite plastic veins none (sphere))))
+   (translate 3.3 1.1 0 (surface wet none (material 0.9 auto g_sWhite plastic spots none (scale 0.8 1.1 0.8 (sphere)))))
+   (translate 0 3.0 -1 (scale 9 0.2 9 (surface matte none (material 0.9 auto g_sEqualWhite plastic clouds none (cube)))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
+ (pointlight -8 -9 12 (scale (blackbody 6500) 4000))
+ (camera stereographic 0 0 9 70)
+ (sampler fastblue))"""
+
+
 # Foggy propagator (TextureMaps.cpp:39-57) around and inside glass, seen through each of the other two cameras
 SCENE_FOG_PERSPECTIVE = """(scene
  (model (makeunion

@@ -279,3 +279,22 @@ def test_adaptive_tile_restatement(rt, oracle):
     assert 0 < sta.refined_blocks < nblk and sta.rays_primary == stf.rays_primary + 1600 * sta.refined_blocks
     changed = np.abs(a - b).max(axis=0) > 0
     assert 0.02 < changed.mean() < 0.98 and np.abs(a - b).max() < 0.5
+
+
+def test_solid_colour_textures_restatement(rt, oracle):
+    """The solid colour textures restated (TextureMaps.cpp:518-683, policy Q13): a textured sphere renders, differs from
+    the untextured one, and SeaScape (whose loop discards what it computes, :497-513) changes nothing."""
+    from conftest import SCENE_COLOUR
+    rd = rt.RtRenderDesc(48, 32, 1.0, 0, 0)
+    def img(text):
+        fs = rt.FrontScene(text, "test", optimize=False)
+        return oracle.OracleScene(fs.desc).render(48, 32, 1, rd, rt.RtStats(), threads=2)[0]
+    a = img(SCENE_COLOUR)
+    assert np.isfinite(a).all() and a.mean() > 1e-3
+    b = img(SCENE_COLOUR.replace(" seascape ", " none "))
+    assert np.array_equal(a, b)
+    plain = SCENE_COLOUR
+    for name in ("voronoi", "agate", "marble", "clouds", "wood", "spots", "veins"):
+        plain = plain.replace(" %s none " % name, " none none ").replace(" %s coloredglass " % name, " none coloredglass ")
+    c = img(plain)
+    assert (np.abs(a - c).max(axis=0) > 1e-4).mean() > 0.3
