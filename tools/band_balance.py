@@ -17,15 +17,20 @@ t0 = time.perf_counter(); gs.render_device(W, H, spp, planes.data_ptr(), 0); tor
 full = time.perf_counter() - t0
 ps = rt.FrontScene(scene, "test", optimize=True)
 prev, _ = rt.GpuScene(ps.desc).render(W // 16, H // 16, 1)
-cost = rt.sharding.row_cost_from_preview(prev, H)
+weights = [float(x) for x in os.environ.get("RT_HIT_WEIGHTS", "").split(",") if x]       # sweep of the cost model's weight
+cands = [("equal", None)] + ([("w%g" % w, w) for w in weights] if weights else [("balanced", "default")])
 for world in (2, 4, 8):
-    for name, bands in (("equal", rt.sharding.row_bands(H, world)), ("balanced", rt.sharding.balanced_bands(cost, world))):
-        ts = []
-        for r in range(world):
-            if bands[r] == bands[r + 1]:
-                ts.append(0.0); continue
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            gs.render_device(W, H, spp, planes.data_ptr(), 0, bands[r], bands[r + 1])
-            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        print("%s world %d %-8s full %.1f ms  slowest band %.1f ms  -> efficiency %.2f   bands %s" %
-              (scene, world, name, 1e3 * full, 1e3 * max(ts), full / (world * max(ts)), bands))
+    for name, wt in cands:
+        if wt is None: bands = rt.sharding.row_bands(H, world)
+        elif wt == "default": bands = rt.sharding.balanced_bands(rt.sharding.row_cost_from_preview(prev, H), world)
+        else: bands = rt.sharding.balanced_bands(rt.sharding.row_cost_from_preview(prev, H, hit_weight=wt), world)
+        if True:
+            ts = []
+            for r in range(world):
+                if bands[r] == bands[r + 1]:
+                    ts.append(0.0); continue
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                gs.render_device(W, H, spp, planes.data_ptr(), 0, bands[r], bands[r + 1])
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            print("%s world %d %-8s full %.1f ms  slowest band %.1f ms  -> efficiency %.2f   bands %s" %
+                  (scene, world, name, 1e3 * full, 1e3 * max(ts), full / (world * max(ts)), bands))
