@@ -399,11 +399,17 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
     const int n = LITE ? (f1 - f0) : P.counters[CTR_SLOW_V];
     int *const work = &P.counters[LITE ? CTR_WORK_V : CTR_WORK_VS];
     const int wlane = threadIdx.x & 63;
+  int wnext = 0, wlimit = 0;      /* the wave's current claim: items [wnext, wlimit) */
   for (;;) {
-    int wbase = 0;
-    if (wlane == 0) wbase = atomicAdd(work, 64);
-    wbase = __shfl(wbase, 0, 64);
-    if (wbase >= n) break;
+    if (wnext >= wlimit) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, RT_CLAIM);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        wnext = b; wlimit = b + RT_CLAIM < n ? b + RT_CLAIM : n;
+    }
+    const int wbase = wnext;
+    wnext += 64;
     const bool live = wbase + wlane < n;
     int f;
     if constexpr (LITE) f = f0 + wbase + wlane;
@@ -592,11 +598,17 @@ __global__ void RT_LB_SHADOW(LITE) k_shadow(const RtDevScene Sv, RtPipe P, int n
     const int n = LITE ? nrays : P.counters[CTR_SLOW_S];
     int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
     const int wlane = threadIdx.x & 63;
+  int wnext = 0, wlimit = 0;      /* the wave's current claim: items [wnext, wlimit) */
   for (;;) {
-    int wbase = 0;
-    if (wlane == 0) wbase = atomicAdd(work, 64);
-    wbase = __shfl(wbase, 0, 64);
-    if (wbase >= n) break;
+    if (wnext >= wlimit) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, RT_CLAIM);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        wnext = b; wlimit = b + RT_CLAIM < n ? b + RT_CLAIM : n;
+    }
+    const int wbase = wnext;
+    wnext += 64;
     const bool live = wbase + wlane < n;
     int s;
     if constexpr (LITE) s = wbase + wlane;

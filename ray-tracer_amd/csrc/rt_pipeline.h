@@ -24,9 +24,14 @@
 enum { GEO_P = 0, GEO_N = 3, GEO_E = 6, GEO_HN = 9, GEO_FNE = 12, GEO_F = 13, GEO_FNT = 14, GEO_ETA = 15, GEO_W2 = 16, GEO_COUNT = 17 };
 enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT = 4 };
 /* [CTR_SHADOW .. CTR_WORK_SS] are cleared together per level; CTR_WORK_*: next unclaimed item of the persistent kernels */
-enum { CTR_FRAMES = 0, CTR_OVERFLOW = 1, CTR_SHADOW = 2, CTR_SLOW_V = 3, CTR_SLOW_S = 4, CTR_WORK_V = 5, CTR_WORK_VS = 6, CTR_WORK_S = 7,
-       CTR_WORK_SS = 8, CTR_PROF = 9, CTR_COUNT = 24 };
-#define CTR_LEVEL_CLEAR 7
+/* every counter sits on a cache line of its own (32 ints): they are hit by same-address atomics from every wave, and
+   atomics on one line serialise in its L2 channel whichever word they touch */
+#define CTR_LINE 32
+enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * CTR_LINE, CTR_SLOW_V = 3 * CTR_LINE, CTR_SLOW_S = 4 * CTR_LINE,
+       CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
+       CTR_COUNT = 10 * CTR_LINE };
+#define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
+#define RT_CLAIM 256        /* items a persistent wave claims per atomic: four 64-item passes */
 
 typedef struct RtPipe {
     int     fcap, scap, ncap;   /* frame, shadow-ray and root capacities */
