@@ -38,6 +38,25 @@ __device__ int wave_alloc(int count, int *counter)
     return base + incl - count;
 }
 
+/* two queues at once: counts a (low half) and b (high half) of one 64-bit counter, one atomic per wave */
+__device__ void wave_alloc2(int count_a, int count_b, int *counter_pair, int &base_a, int &base_b)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long incl = (unsigned long long)(unsigned)count_a | ((unsigned long long)(unsigned)count_b << 32);
+    const unsigned long long own = incl;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const unsigned long long total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 63 && total != 0) base = atomicAdd((unsigned long long *)counter_pair, total);
+    base = __shfl(base, 63, 64);
+    const unsigned long long mine = base + incl - own;      /* no carry between the halves: both queues hold < 2^31 entries */
+    base_a = (int)(unsigned)(mine & 0xFFFFFFFFull);
+    base_b = (int)(unsigned)(mine >> 32);
+}
+
 /* Frame and queue arrays are streamed: written once by one kernel, read once by the next.  Non-temporal accesses
    keep them from displacing the per-lane private memory (hit arenas) that the tracing kernels re-use from L2. */
 template <typename T> RT_DEV void nt_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
@@ -549,13 +568,15 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
             if (tr_one) flags |= FR_TR_ONE; else spec_store(P.f_tr, P.fcap, f, tr);
         }
     }
+    /* append this lane's shadow rays to the queue and (LITE) the frame to the slow list: one atomic per wave for both */
+    int base;
     if constexpr (LITE) {
         if (bail) { n_shadow = 0; mask = 0; }
-        int slot = wave_alloc(bail ? 1 : 0, &P.counters[CTR_SLOW_V]);
+        int slot;
+        wave_alloc2(n_shadow, bail ? 1 : 0, &P.counters[CTR_SHADOW], base, slot);
         if (bail) P.slow_v[slot] = f;
-    }
-    /* append this lane's shadow rays to the queue: one atomic per wave */
-    int base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
+    } else
+        base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
     for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 16 cycles */

@@ -27,7 +27,8 @@ enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT 
 /* every counter sits on a cache line of its own (32 ints): they are hit by same-address atomics from every wave, and
    atomics on one line serialise in its L2 channel whichever word they touch */
 #define CTR_LINE 32
-enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * CTR_LINE, CTR_SLOW_V = 3 * CTR_LINE, CTR_SLOW_S = 4 * CTR_LINE,
+/* CTR_SHADOW and CTR_SLOW_V are the two halves of one 64-bit word: k_visual bumps both with a single atomic (wave_alloc2) */
+enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * CTR_LINE, CTR_SLOW_V = 2 * CTR_LINE + 1, CTR_SLOW_S = 4 * CTR_LINE,
        CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
        CTR_COUNT = 10 * CTR_LINE };
 #define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
