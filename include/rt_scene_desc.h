@@ -92,7 +92,7 @@ typedef struct RtCamera {       /* Cameras.h:8-67 */
     double  focus_distance;
 } RtCamera;
 
-enum RtSamplerType { RT_SAMPLER_TEST = 0, RT_SAMPLER_FASTBLUE = 1, RT_SAMPLER_JITTER = 2, RT_SAMPLER_BLUENOISE = 3, RT_SAMPLER_ADAPTIVEBLUE = 4 };
+enum RtSamplerType { RT_SAMPLER_TEST = 0, RT_SAMPLER_FASTBLUE = 1, RT_SAMPLER_JITTER = 2, RT_SAMPLER_BLUENOISE = 3, RT_SAMPLER_ADAPTIVEBLUE = 4, RT_SAMPLER_DEBUG = 5 };
 typedef struct RtSampler {      /* Sampling.h; Sampling.cpp:324-348, 474-548 */
     int32_t type;
     int32_t venera;             /* nVenera: vRGB instead of sRGB */

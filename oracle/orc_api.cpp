@@ -672,6 +672,15 @@ extern "C" int orc_render(void *h, const RtRenderDesc *rd, float *planes, float 
                 if (sample_rgb_out) { float *o = sample_rgb_out + 3 * ((size_t)j * W + i); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
             }
         ns = (long)W * H;
+    } else if (s->sampler_type == RT_SAMPLER_DEBUG) {
+        /* DebugSamplingTile::Render, Sampling.cpp:356-372: one (verbose, in the reference) ray through the centre fills the image */
+        Ctx cx;
+        for (int k = 0; k < 6; k++) cx.aux[k] = s->aux_init[k];
+        Rgb c = sample_rgb(*s, 0.5, 0.5, cx);
+        np += cx.n_primary; nsh += cx.n_shadow; nsec += cx.n_secondary;
+        for (size_t i = 0; i < (size_t)W * H; i++) { planes[i] = c.r; planes[(size_t)W * H + i] = c.g; planes[2 * (size_t)W * H + i] = c.b; }
+        if (sample_rgb_out) { sample_rgb_out[0] = c.r; sample_rgb_out[1] = c.g; sample_rgb_out[2] = c.b; }
+        ns = 1;
     } else if (s->sampler_type == RT_SAMPLER_JITTER) {
         /* JitterSamplingTile::Render, Sampling.cpp:394-419: one sample per supersample pixel at a random position drawn
            from the global MWC stream (y before x, RandomDouble = two RandomUnsigned, high word first), SetRGB, then

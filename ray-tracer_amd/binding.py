@@ -10,7 +10,7 @@ LIB_RT = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")   # 
 LIB_FRONTEND = os.path.join(HERE, "librt_frontend.so")
 TABLES = os.path.join(HERE, "data", "tables.bin")
 NSPEC = 10
-RT_SAMPLER_TEST, RT_SAMPLER_FASTBLUE, RT_SAMPLER_JITTER, RT_SAMPLER_BLUENOISE, RT_SAMPLER_ADAPTIVEBLUE = 0, 1, 2, 3, 4      # enum RtSamplerType, include/rt_scene_desc.h
+RT_SAMPLER_TEST, RT_SAMPLER_FASTBLUE, RT_SAMPLER_JITTER, RT_SAMPLER_BLUENOISE, RT_SAMPLER_ADAPTIVEBLUE, RT_SAMPLER_DEBUG = 0, 1, 2, 3, 4, 5      # enum RtSamplerType, include/rt_scene_desc.h
 BLUE_N = 1600
 
 

@@ -81,6 +81,11 @@ __device__ void sample_at(const RtDevScene &S, const RtSampleGrid &g, int64_t s,
         for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
         return;
     }
+    if (g.sampler == RT_SAMPLER_DEBUG) {                /* DebugSamplingTile::Render, Sampling.cpp:356-372: one ray through the image centre */
+        v2[0] = 0.5; v2[1] = 0.5; pos2[0] = 0.5 * g.width; pos2[1] = 0.5 * g.height;
+        for (int k = 0; k < 6; k++) aux[k] = S.aux_init[k];
+        return;
+    }
     if (g.sampler == RT_SAMPLER_JITTER) {               /* JitterSamplingTile::Render, Sampling.cpp:404-413 */
         const int n = g.nW, nHi = g.nH;
         const int jl = (int)(s / n), i = (int)(s - (int64_t)jl * n), j = g.jit_row0 + jl;
@@ -1362,6 +1367,15 @@ __global__ void __launch_bounds__(256) k_store_test(const float *sample_rgb, int
     if (i >= width || j >= row1) return;
     const float *c = sample_rgb + 3 * ((size_t)(j - row0) * width + i);
     for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] = c[k];
+}
+
+/* DebugSamplingTile: im.FillRGB(rgb) with the one sample (Sampling.cpp:369) */
+__global__ void __launch_bounds__(256) k_fill_debug(const float *sample_rgb, int width, int height, int row0, int row1, float *planes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = row0 + blockIdx.y;
+    if (i >= width || j >= row1) return;
+    for (int k = 0; k < 3; k++) planes[((size_t)k * height + j) * width + i] = sample_rgb[k];
 }
 
 /* JitterSamplingTile: im2.SetRGB(rad.sRGB(), i, j) (Sampling.cpp:412): per-sample RGB in row-major sample order -> planes */

@@ -532,6 +532,8 @@ struct SamplingTile {
     virtual int  DeviceSampler() const = 0;     /* RtSamplerType, -1 if this tile has no device path yet */
 };
 struct TestSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_TEST; } };
+/* DebugSamplingTile (Sampling.cpp:350-386): one ray through the image centre, the image filled with its colour */
+struct DebugSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_DEBUG; } };
 /* JitterSamplingTile (Sampling.cpp:388-419): one sample per supersample pixel, jittered by the global MWC stream */
 struct JitterSamplingTile : SamplingTile { int DeviceSampler() const { return RT_SAMPLER_JITTER; } };
 /* BlueNoiseSamplingTile (Sampling.cpp:421-466): tiles of 40/sqrt(spp) output pixels, per-sample Kaiser splat */

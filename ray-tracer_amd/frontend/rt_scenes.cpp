@@ -373,6 +373,7 @@ struct Parser {
             else if (w == "sampler") {
                 std::string k = word();
                 if (k == "test") rt->psSample = new TestSamplingTile;
+                else if (k == "debug") rt->psSample = new DebugSamplingTile;
                 else if (k == "jitter") rt->psSample = new JitterSamplingTile;
                 else if (k == "bluenoise") rt->psSample = new BlueNoiseSamplingTile;
                 else if (k == "adaptive") { rt->psSample = new AdaptiveBlueSamplingTile; if (!peek_close()) rt->psSample->QIndex1((int)num()); }
@@ -416,6 +417,7 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     }
     if (rc) { delete s; return 0; }
     if (sampler && !strcmp(sampler, "test")) s->rt.psSample = new TestSamplingTile;
+    else if (sampler && !strcmp(sampler, "debug")) s->rt.psSample = new DebugSamplingTile;
     else if (sampler && !strcmp(sampler, "jitter")) s->rt.psSample = new JitterSamplingTile;
     else if (sampler && !strcmp(sampler, "bluenoise")) s->rt.psSample = new BlueNoiseSamplingTile;
     else if (sampler && !strcmp(sampler, "adaptive")) s->rt.psSample = new AdaptiveBlueSamplingTile;

@@ -135,6 +135,19 @@ def test_radiance_matches_oracle(gpu, oracle, scene, tol):
         assert _rel_rmse(a[~bad], b[~bad]) <= tol
 
 
+def test_debug_tile(gpu, oracle):
+    """a1 DebugSamplingTile (Sampling.cpp:356-372): one ray through the image centre, the image filled with its colour;
+    returns 1."""
+    opt, raw, g, o = _pair(gpu, oracle, "S1", "debug")
+    img, st = g.render(40, 24, 16)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(40, 24, 16, gpu.RtRenderDesc(40, 24, 16.0, 0, 0), ost)
+    assert st.samples == n == 1 and st.rays() == ost.rays() and st.rays_primary == 1
+    assert np.abs(img - ref).max() <= 2e-6 and np.ptp(img.reshape(3, -1), axis=1).max() == 0.0 and img.max() > 0
+    band, _ = g.render(40, 24, 16, row0=5, row1=9)
+    assert np.array_equal(band[:, 5:9, :], img[:, 5:9, :])
+
+
 def test_solid_colour_textures(gpu, oracle):
     """8f-3 the solid colour textures (TextureMaps.cpp:518-683: Voronoi, Agate, Marble, Clouds, Wood, Spots, Veins) and
     the scalar BandNoise / FractalNoise / Voronoi they are built on (a15), with the stated policy Q13 (the colour belongs to
