@@ -41,7 +41,11 @@ enum RtNodeType {
     RT_NODE_MATERIAL     = 12,  /* left=psChild; data: fDensity,fRefractiveIndex,color[10];
                                    i0: nLuster, i1: texture id, i2: propagator id; link=paAffineTransforms  Solids.h:269-291 */
     RT_NODE_SURFACE      = 13,  /* left=psChild; i0: nRoughness, i1: texture id; link=paAffineTransforms   Solids.h:201-212 */
-    RT_NODE_CONEHYPERCYL = 14   /* Quadric with own GetExtent; data: P,Q,R,Rneck; i0: nClip      Solids.h:116-121 */
+    RT_NODE_CONEHYPERCYL = 14,  /* Quadric with own GetExtent; data: P,Q,R,Rneck; i0: nClip      Solids.h:116-121 */
+    RT_NODE_MESH         = 15   /* closed triangle mesh as a Solid.  data: 3*i0 vertex coordinates, then 3*i1 vertex indices
+                                   (0-based, stored as doubles); i0: nVertices, i1: nTriangles.  The reference holds meshes
+                                   (ObjectFormat.cpp:12-28, LoadObjFile :31-75) and a Moeller-Trumbore test (:79-102) but never
+                                   makes them a Solid: policy Q14 in DESIGN.md says how this node behaves. */
 };
 
 /* SURF_* (Solids.h:187-192) and MAT_* (Solids.h:214-224) keep the reference's integer values. */

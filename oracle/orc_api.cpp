@@ -190,6 +190,18 @@ extern "C" void *orc_scene_create(const RtSceneDesc *d, int run_optimize)
             for (int k = 0; k < rn.i0; k++) n->planes.push_back(V3(p[3 * k], p[3 * k + 1], p[3 * k + 2]));
             break;
         case RT_NODE_TORUS:        n->minor = p[0]; break;
+        case RT_NODE_MESH:
+            for (int k = 0; k < rn.i0; k++) {
+                V3 v(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                n->mverts.push_back(v);
+                if (k == 0) n->ex.lo = n->ex.hi = v;            /* ObjectFormat.cpp:51-56 */
+                else {
+                    n->ex.lo = V3(v.x < n->ex.lo.x ? v.x : n->ex.lo.x, v.y < n->ex.lo.y ? v.y : n->ex.lo.y, v.z < n->ex.lo.z ? v.z : n->ex.lo.z);
+                    n->ex.hi = V3(v.x > n->ex.hi.x ? v.x : n->ex.hi.x, v.y > n->ex.hi.y ? v.y : n->ex.hi.y, v.z > n->ex.hi.z ? v.z : n->ex.hi.z);
+                }
+            }
+            for (int k = 0; k < 3 * rn.i1; k++) n->mtris.push_back((int)p[3 * (size_t)rn.i0 + k]);
+            break;
         case RT_NODE_AFFINE:
             for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { n->m.m[r][c] = p[3 * r + c]; n->mi.m[r][c] = p[9 + 3 * r + c]; }
             n->tr = V3(p[18], p[19], p[20]);

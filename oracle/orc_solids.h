@@ -65,6 +65,9 @@ struct Node {
     /* primitive parameters */
     double  P, Q, R, Rneck, minor;
     std::vector<V3> planes;
+    /* triangle mesh (policy Q14): vertices, 3 vertex indices per triangle; its extent is kept in ex */
+    std::vector<V3>  mverts;
+    std::vector<int> mtris;
     /* affine */
     M3      m, mi;
     V3      tr;

@@ -253,7 +253,8 @@ RT_DEV void list_reload_top(Arena &A)
 RT_DEV void list_retag_top(Arena &A, int tag) { A.l_tag[A.nlist - 1] = tag; A.t_tag = tag; }
 
 /* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
-__device__ void hit_list(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
+template <class W>
+__device__ void hit_list(W &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
 {
     int first, origin_inside;
     for (first = 0; first < w.count; first++)
@@ -557,6 +558,108 @@ RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena 
     hit_list(w, A, tag, prim, tp.leaf_affine);
 }
 
+/* ------------------------------------------------------------------ triangle meshes (policy Q14)
+ * A closed mesh is a Solid whose boundary crossings are the ray's triangle hits.  Per triangle: the Moeller-Trumbore
+ * test in the form of ObjectFormat.cpp:79-102, with its two slips put right (the second barycentric test is
+ * u + v > 1, and t = f * Dot(e2, q)) and its parallel test made scale free (|cos| < EPSILON instead of |a| < EPSILON,
+ * which would delete every triangle of a fine mesh).  Crossings ahead of the origin (t >= 0) are gathered through the
+ * mesh's BVH, the RT_MESH_MAXHITS nearest kept in (t, triangle) order, and handed to HitList as any solver's roots
+ * are; an odd number of them means the origin is inside, which HitList is told by one root behind the origin. */
+struct MeshWork {
+    double r[RT_MESH_MAXHITS + 3];
+    D3     n[RT_MESH_MAXHITS + 3];
+    int    count;
+    int    inside_inf;
+    double eps;
+};
+RT_DEV bool mesh_triangle(const RtMeshTri &T, const DRay &ray, double &t)
+{
+    const D3 e1 = d3(T.e1[0], T.e1[1], T.e1[2]), e2 = d3(T.e2[0], T.e2[1], T.e2[2]);
+    const D3 h = cross(ray.dir, e2);
+    const double a = dot(e1, h);
+    const D3 nn = cross(e1, e2);
+    if (a * a < (RT_EPSILON * RT_EPSILON) * (dot(nn, nn) * dot(ray.dir, ray.dir))) return false;
+    const double f = 1.0 / a;
+    const D3 s = ray.org - d3(T.v0[0], T.v0[1], T.v0[2]);
+    const double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    const D3 q = cross(s, e1);
+    const double v = f * dot(ray.dir, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = f * dot(e2, q);
+    return t >= 0.0;
+}
+RT_DEV bool mesh_box_hit(const RtMeshNode &nd, const DRay &ray)
+{
+    double t0 = 0.0, t1 = RT_INFINITY;
+    const double o[3] = { ray.org.x, ray.org.y, ray.org.z }, d[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double lo = (double)nd.lo[k], hi = (double)nd.hi[k];
+        if (d[k] != 0.0) {
+            const double inv = 1.0 / d[k];
+            double ta = (lo - o[k]) * inv, tb = (hi - o[k]) * inv;
+            if (ta > tb) { const double x = ta; ta = tb; tb = x; }
+            /* one part in 1e9 of slack on top of the padded boxes: the division above is not the arithmetic of the triangle test */
+            ta -= fabs(ta) * 1e-9; tb += fabs(tb) * 1e-9;
+            if (ta > t0) t0 = ta;
+            if (tb < t1) t1 = tb;
+        } else if (o[k] < lo || o[k] > hi) return false;
+    }
+    return t0 <= t1;
+}
+RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag)
+{
+    const RtMeshInfo mi = S.meshes[mp.plane0];
+    const RtMeshNode *nodes = S.mesh_nodes + mi.node0;
+    const RtMeshTri *tris = S.mesh_tris + mi.tri0;
+    double ht[RT_MESH_MAXHITS];
+    int    hq[RT_MESH_MAXHITS];         /* position in tris[] */
+    int    nh = 0, total = 0;
+    int    stack[RT_MESH_STACK];
+    int    sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const RtMeshNode nd = nodes[stack[--sp]];
+        if (!mesh_box_hit(nd, ray)) continue;
+        if (nd.a >= 0) {
+            if (sp + 2 > RT_MESH_STACK) { A.overflow = 1; break; }
+            stack[sp++] = nd.b;
+            stack[sp++] = nd.a;
+            continue;
+        }
+        const int first = ~nd.a;
+        for (int q = first; q < first + nd.b; q++) {
+            double t;
+            if (!mesh_triangle(tris[q], ray, t)) continue;
+            total++;
+            const int id = tris[q].id;
+            /* insert into the sorted nearest-RT_MESH_MAXHITS set, order (t, triangle id) */
+            int j = nh;
+            if (nh == RT_MESH_MAXHITS) {
+                const int l = nh - 1;
+                if (t > ht[l] || (t == ht[l] && id > tris[hq[l]].id)) continue;
+                j = l;
+            } else nh++;
+            for (; j > 0 && (t < ht[j - 1] || (t == ht[j - 1] && id < tris[hq[j - 1]].id)); --j) { ht[j] = ht[j - 1]; hq[j] = hq[j - 1]; }
+            ht[j] = t; hq[j] = q;
+        }
+    }
+    if (total > RT_MESH_MAXHITS) A.overflow = 1;
+    if (nh == 0) return;
+    MeshWork w;
+    w.inside_inf = 0; w.eps = RT_EPSILON;
+    const int behind = nh & 1;                  /* odd number of crossings ahead: the origin is inside */
+    if (behind) { WR(w, 0) = -1.0; WN(w, 0) = d3(0.0, 0.0, 0.0); }
+    for (int i = 0; i < nh; i++) {
+        const RtMeshTri &T = tris[hq[i]];
+        WR(w, behind + i) = ht[i];
+        WN(w, behind + i) = cross(d3(T.e1[0], T.e1[1], T.e1[2]), d3(T.e2[0], T.e2[1], T.e2[2]));
+    }
+    w.count = nh + behind;
+    hit_list(w, A, tag, prim, mp.leaf_affine);
+}
+
 /* ================================================================== CSG merge (Solids.cpp:987-1058) */
 enum { MERGE_MAX = 0, MERGE_MIN = 1, MERGE_DIFF = 2 };
 RT_DEV uint16_t mat_op(int op, uint16_t l, uint16_t r, const RtMaterialDev *mats)
@@ -847,6 +950,9 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         case OP_TORUS:
             if constexpr (LITE) { A.bail = 1; goto done; }
             else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
+        case OP_MESH:
+            if constexpr (LITE) { A.bail = 1; goto done; }
+            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -944,7 +1050,8 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 default:
                     if constexpr (LITE) { A.bail = 1; goto done; }
                     else {
-                        torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
+                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag);
+                        else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
                         break;

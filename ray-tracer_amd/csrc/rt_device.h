@@ -48,7 +48,8 @@ enum RtOp {
     OP_RETAG,       /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
     OP_REGION,      /* a: union region index, tag: consumer of the region's result */
     OP_RET,         /* a: union region index: end of one region child's code */
-    OP_CHAIN        /* a: chain index: [box] affine* primitive (material|surface)* in one step; b != 0: followed by the region's OP_RET */
+    OP_CHAIN,       /* a: chain index: [box] affine* primitive (material|surface)* in one step; b != 0: followed by the region's OP_RET */
+    OP_MESH         /* a: primitive index (RtPrim.plane0 = mesh index): closed triangle mesh, policy Q14 */
 };
 
 /* Every instruction that leaves a list names its consumer: tag = 2 * (consumer pc) + side (0 left / only, 1 right). */
@@ -156,6 +157,25 @@ typedef struct RtChain {
     int32_t wrap_tex[RT_CHAIN_WRAPS];   /* texture call-out the wrapper queues, -1 none */
 } RtChain;
 
+/* Triangle meshes (policy Q14).  One binary BVH per mesh over its triangles, in the mesh's own frame; boxes are floats
+   rounded outward (one 32-byte node per load), triangles are stored in leaf order as (v0, e1, e2) with the edges
+   subtracted once on the host -- ObjectFormat.cpp:85-86 subtracts them per test, same doubles either way. */
+#define RT_MESH_MAXHITS 16          /* MAXHITS, Solids.h:20: crossings kept per ray and mesh (the nearest ones) */
+#define RT_MESH_STACK   64          /* pending BVH nodes per ray */
+#define RT_MESH_LEAF    4           /* triangles per leaf at most */
+typedef struct RtMeshNode {
+    float   lo[3], hi[3];
+    int32_t a, b;           /* inner: a, b = children (node indices relative to the mesh's first node); leaf: a = ~(first triangle), b = count */
+} RtMeshNode;
+typedef struct RtMeshTri {
+    double  v0[3], e1[3], e2[3];
+    int32_t id, pad_;       /* index in the file's order: breaks ties between equal t */
+} RtMeshTri;
+typedef struct RtMeshInfo {
+    int64_t node0, tri0;    /* first node / triangle of this mesh in the scene's arrays */
+    int32_t n_nodes, n_tris;
+} RtMeshInfo;
+
 typedef struct RtLightDev {
     double  org[3], vA[3], vB[3];
     float   flux[RT_NSPEC];
@@ -200,4 +220,8 @@ typedef struct RtDevScene {
     double  aux_init[6];
     float   tex_palette[5][RT_NSPEC];   /* g_sGreen, g_sEqualWhite, g_sOrange, g_sRed, g_sBlue: the solid colour textures' spectra */
     float   fractal_omega19;            /* powf(1.9f, -1.0f) from the host's libm (FractalNoise of the solid textures) */
+    int32_t n_meshes;
+    const RtMeshInfo *meshes;
+    const RtMeshNode *mesh_nodes;
+    const RtMeshTri  *mesh_tris;
 } RtDevScene;

@@ -151,6 +151,13 @@ struct Flattener {
         case RT_NODE_POLYHEDRON: return polyhedron_bound(p, n.i0);
         case RT_NODE_SLAB: return Box::cube(-kHuge, -kHuge, -1.0, kHuge, kHuge, 1.0);
         case RT_NODE_TORUS: return Box::cube(-1.0 - p[0], -1.0 - p[0], -p[0], 1.0 + p[0], 1.0 + p[0], p[0]);
+        case RT_NODE_MESH: {
+            if (n.i0 < 1 || n.i1 < 1) return Box();
+            double lo[3] = { p[0], p[1], p[2] }, hi[3] = { p[0], p[1], p[2] };
+            for (int v = 1; v < n.i0; v++)
+                for (int k = 0; k < 3; k++) { double x = p[3 * v + k]; if (x < lo[k]) lo[k] = x; if (x > hi[k]) hi[k] = x; }
+            return Box::cube(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+        }
         case RT_NODE_AFFINE: return box_transform(local_bound(n.left), p, p + 18);
         case RT_NODE_UNION: case RT_NODE_TOPUNION: return box_union(local_bound(n.left), local_bound(n.right));
         case RT_NODE_INTERSECTION: return box_intersect(local_bound(n.left), local_bound(n.right));
@@ -209,8 +216,98 @@ struct Flattener {
             o.planes.insert(o.planes.end(), p, p + 3 * n.i0);
             if (n.i0 < 1) fail(RT_ERR_INVALID, "polyhedron without planes");
         }
+        else if (type_op == OP_MESH) pr.plane0 = build_mesh(i);
         o.prims.push_back(pr);
         return (int)o.prims.size() - 1;
+    }
+    /* binary BVH over the triangles of mesh node i: median split of the centroids along the widest axis */
+    struct MeshBuild {
+        const double *v; const double *f;
+        std::vector<int> order;
+        std::vector<float> cen;         /* 3 per triangle */
+        std::vector<RtMeshNode> *nodes;
+        size_t node0;
+        void tri_box(int t, double lo[3], double hi[3]) const
+        {
+            for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+            for (int c = 0; c < 3; c++) {
+                const double *q = v + 3 * (size_t)f[3 * (size_t)t + c];
+                for (int k = 0; k < 3; k++) { if (q[k] < lo[k]) lo[k] = q[k]; if (q[k] > hi[k]) hi[k] = q[k]; }
+            }
+        }
+        int build(int first, int count)
+        {
+            const int me = (int)(nodes->size() - node0);
+            nodes->push_back(RtMeshNode());
+            double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+            float clo[3] = { 3e38f, 3e38f, 3e38f }, chi[3] = { -3e38f, -3e38f, -3e38f };
+            for (int q = first; q < first + count; q++) {
+                double a[3], b[3];
+                tri_box(order[q], a, b);
+                for (int k = 0; k < 3; k++) {
+                    if (a[k] < lo[k]) lo[k] = a[k];
+                    if (b[k] > hi[k]) hi[k] = b[k];
+                    float c = cen[3 * (size_t)order[q] + k];
+                    if (c < clo[k]) clo[k] = c;
+                    if (c > chi[k]) chi[k] = c;
+                }
+            }
+            RtMeshNode nd;
+            for (int k = 0; k < 3; k++) {       /* outward: a relative pad, then the float on the far side */
+                double e = 1e-6 * (hi[k] - lo[k]) + 1e-7 * (fabs(lo[k]) + fabs(hi[k])) + 1e-12;
+                float l = (float)(lo[k] - e), h = (float)(hi[k] + e);
+                if ((double)l > lo[k] - e) l = nextafterf(l, -INFINITY);
+                if ((double)h < hi[k] + e) h = nextafterf(h, INFINITY);
+                nd.lo[k] = l; nd.hi[k] = h;
+            }
+            if (count <= RT_MESH_LEAF) { nd.a = ~first; nd.b = count; (*nodes)[node0 + me] = nd; return me; }
+            int ax = 0;
+            if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+            if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+            const int half = count / 2;
+            const std::vector<float> &C = cen;
+            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
+                             [&C, ax](int x, int y) { float cx = C[3 * (size_t)x + ax], cy = C[3 * (size_t)y + ax]; return cx < cy || (cx == cy && x < y); });
+            int l = build(first, half);
+            int r = build(first + half, count - half);
+            nd.a = l; nd.b = r;
+            (*nodes)[node0 + me] = nd;
+            return me;
+        }
+    };
+    int build_mesh(int i)
+    {
+        const RtNode &n = N(i);
+        const double *p = D(i);
+        const int nv = n.i0, nt = n.i1;
+        if (nv < 3 || nt < 1 || n.ndata != 3 * nv + 3 * nt) { fail(RT_ERR_INVALID, "mesh node with inconsistent sizes"); return -1; }
+        const double *f = p + 3 * (size_t)nv;
+        for (size_t k = 0; k < 3 * (size_t)nt; k++)
+            if (!(f[k] >= 0.0 && f[k] < (double)nv) || f[k] != floor(f[k])) { fail(RT_ERR_INVALID, "mesh vertex index out of range"); return -1; }
+        for (size_t k = 0; k < 3 * (size_t)nv; k++) if (!(fabs(p[k]) < 1e30)) { fail(RT_ERR_INVALID, "mesh vertex is not finite"); return -1; }
+        MeshBuild mb;
+        mb.v = p; mb.f = f; mb.nodes = &o.mesh_nodes; mb.node0 = o.mesh_nodes.size();
+        mb.order.resize(nt); mb.cen.resize(3 * (size_t)nt);
+        for (int t = 0; t < nt; t++) {
+            mb.order[t] = t;
+            double a[3], b[3];
+            mb.tri_box(t, a, b);
+            for (int k = 0; k < 3; k++) mb.cen[3 * (size_t)t + k] = (float)(0.5 * (a[k] + b[k]));
+        }
+        RtMeshInfo mi;
+        mi.node0 = (int64_t)o.mesh_nodes.size(); mi.tri0 = (int64_t)o.mesh_tris.size(); mi.n_tris = nt;
+        mb.build(0, nt);
+        mi.n_nodes = (int)(o.mesh_nodes.size() - mb.node0);
+        o.mesh_tris.resize((size_t)mi.tri0 + nt);
+        for (int q = 0; q < nt; q++) {
+            const int t = mb.order[q];
+            const double *v0 = p + 3 * (size_t)f[3 * (size_t)t], *v1 = p + 3 * (size_t)f[3 * (size_t)t + 1], *v2 = p + 3 * (size_t)f[3 * (size_t)t + 2];
+            RtMeshTri &T = o.mesh_tris[(size_t)mi.tri0 + q];
+            for (int k = 0; k < 3; k++) { T.v0[k] = v0[k]; T.e1[k] = v1[k] - v0[k]; T.e2[k] = v2[k] - v0[k]; }
+            T.id = t; T.pad_ = 0;
+        }
+        o.meshes.push_back(mi);
+        return (int)o.meshes.size() - 1;
     }
     int tex_node(int tex_id, int link_node)
     {
@@ -416,6 +513,7 @@ struct Flattener {
         else if (lt == RT_NODE_POLYHEDRON) op = OP_POLY;
         else if (lt == RT_NODE_SLAB) op = OP_SLAB;
         else if (lt == RT_NODE_TORUS) op = OP_TORUS;
+        else if (lt == RT_NODE_MESH) op = OP_MESH;
         else return false;
         if (na > 1 || nw > RT_CHAIN_WRAPS) return false;
         if ((int)affine_stack.size() + na > RT_MAX_AFFINE_DEPTH) return false;      /* let the general code report it */
@@ -497,7 +595,7 @@ struct Flattener {
         if (try_chain(i, tag, no_root_bound)) return;
         const RtNode &n = N(i);
         int bound_pc = -1;
-        bool is_leaf = (n.type >= RT_NODE_QUADRIC && n.type <= RT_NODE_TORUS) || n.type == RT_NODE_CONEHYPERCYL;
+        bool is_leaf = (n.type >= RT_NODE_QUADRIC && n.type <= RT_NODE_TORUS) || n.type == RT_NODE_CONEHYPERCYL || n.type == RT_NODE_MESH;
         /* a box in front of: every leaf, every affine, every binary node (not in front of pure wrappers: same box as their child) */
         bool boxed = with_bounds && !no_root_bound && (is_leaf || n.type == RT_NODE_AFFINE || (n.type >= RT_NODE_UNION && n.type <= RT_NODE_DIFFERENCE));
         if (boxed) {
@@ -510,6 +608,7 @@ struct Flattener {
         case RT_NODE_POLYHEDRON: push(OP_POLY, leaf(OP_POLY, i), 0, tag); break;
         case RT_NODE_SLAB: push(OP_SLAB, leaf(OP_SLAB, i), 0, tag); break;
         case RT_NODE_TORUS: push(OP_TORUS, leaf(OP_TORUS, i), 0, tag); break;
+        case RT_NODE_MESH: push(OP_MESH, leaf(OP_MESH, i), 0, tag); break;
         case RT_NODE_AFFINE: {
             const double *p = D(i);
             RtAffine a;

@@ -19,6 +19,9 @@ struct RtFlatScene {
     std::vector<RtBvhNode>     bvh;
     std::vector<RtChain>       chains;
     std::vector<int32_t>       region_child_pc, region_always, region_lca;
+    std::vector<RtMeshInfo>    meshes;
+    std::vector<RtMeshNode>    mesh_nodes;
+    std::vector<RtMeshTri>     mesh_tris;
     int  irregular_leaves;      /* leaves whose recorded affine is not their innermost enclosing affine */
     int  culled_subtrees;       /* OP_BOUND instructions emitted */
     RtFlatScene() : irregular_leaves(0), culled_subtrees(0) {}

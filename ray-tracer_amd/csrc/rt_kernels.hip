@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
         if (op == OP_CHAIN) {
             int b = S.chains[S.prog[pc].a].box;
             if (b >= 0) hit = cull_box_hit(S.boxes[b].lo, S.boxes[b].hi, cr);
-        } else if (op >= OP_QUADRIC && op <= OP_TORUS) {
+        } else if ((op >= OP_QUADRIC && op <= OP_TORUS) || op == OP_MESH) {
             if (pc > 0 && S.prog[pc - 1].op == OP_BOUND) hit = cull_box_hit(S.boxes[S.prog[pc - 1].a].lo, S.boxes[S.prog[pc - 1].a].hi, cr);
         } else continue;
         nleaves++;

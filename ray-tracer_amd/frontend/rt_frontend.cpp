@@ -558,6 +558,118 @@ int Torus::Emit(RtSerializer &s)
     s.push(&fMinorRadius, 1); s.nodes[i].ndata = 1;
     return i;
 }
+void MeshSolid::AddVertex(double x, double y, double z)
+{
+    Point3 p(x, y, z);
+    if (rgfVertices.empty()) e = Extent(p, p);
+    else { e.pMin = Min(e.pMin, p); e.pMax = Max(e.pMax, p); }          /* ObjectFormat.cpp:51-56 */
+    rgfVertices.push_back(x); rgfVertices.push_back(y); rgfVertices.push_back(z);
+}
+int MeshSolid::LoadObjText(const char *sz)
+{
+    const char *p = sz;
+    while (*p) {
+        const char *eol = strchr(p, '\n');
+        std::string line(p, eol ? (size_t)(eol - p) : strlen(p));
+        p = eol ? eol + 1 : p + line.size();
+        if (line.size() > 2 && line[0] == 'v' && line[1] == ' ') {
+            double x, y, z;
+            if (sscanf(line.c_str(), "v %lf%lf%lf", &x, &y, &z) != 3) return 0;
+            AddVertex(x, y, z);
+        } else if (line.size() > 2 && line[0] == 'f' && line[1] == ' ') {
+            int a, b, c, t;
+            if (sscanf(line.c_str(), "f %d/%d %d/%d %d/%d", &a, &t, &b, &t, &c, &t) != 6 &&
+                sscanf(line.c_str(), "f %d %d %d", &a, &b, &c) != 3) return 0;
+            const int n = nVertices();
+            if (a < 1 || b < 1 || c < 1 || a > n || b > n || c > n) return 0;
+            AddTriangle(a - 1, b - 1, c - 1);
+        }
+    }
+    return nVertices();
+}
+int MeshSolid::LoadObjFile(const char *szFile)
+{
+    FILE *pf = fopen(szFile, "r");
+    if (!pf) return 0;
+    std::string all;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, pf)) > 0) all.append(buf, n);
+    fclose(pf);
+    return LoadObjText(all.c_str());
+}
+int MeshSolid::Emit(RtSerializer &s)
+{
+    int i = s.add(RT_NODE_MESH, this);
+    if (!rgfVertices.empty()) s.push(&rgfVertices[0], (int)rgfVertices.size());
+    std::vector<double> idx(rgnTriangles.begin(), rgnTriangles.end());
+    if (!idx.empty()) s.push(&idx[0], (int)idx.size());
+    s.nodes[i].ndata = (int)(rgfVertices.size() + idx.size());
+    s.nodes[i].i0 = nVertices(); s.nodes[i].i1 = nTriangles();
+    return i;
+}
+MeshSolid *MeshSphere(int nu, int nv)
+{
+    MeshSolid *m = new MeshSolid;
+    if (nu < 3) nu = 3;
+    if (nv < 2) nv = 2;
+    m->AddVertex(0.0, 0.0, 1.0);                               /* north pole: 0 */
+    for (int j = 1; j < nv; j++) {
+        double th = D_PI * j / nv;
+        for (int i = 0; i < nu; i++) {
+            double ph = 2.0 * D_PI * i / nu;
+            m->AddVertex(sin(th) * cos(ph), sin(th) * sin(ph), cos(th));
+        }
+    }
+    m->AddVertex(0.0, 0.0, -1.0);                              /* south pole */
+    const int south = 1 + (nv - 1) * nu;
+    for (int i = 0; i < nu; i++) {
+        int i1 = (i + 1) % nu;
+        m->AddTriangle(0, 1 + i, 1 + i1);
+        for (int j = 0; j + 2 < nv; j++) {
+            int a = 1 + j * nu + i, b = 1 + j * nu + i1, c = 1 + (j + 1) * nu + i, d = 1 + (j + 1) * nu + i1;
+            m->AddTriangle(a, c, d);
+            m->AddTriangle(a, d, b);
+        }
+        m->AddTriangle(south, 1 + (nv - 2) * nu + i1, 1 + (nv - 2) * nu + i);
+    }
+    return m;
+}
+MeshSolid *MeshTorus(int nu, int nv, double r)
+{
+    MeshSolid *m = new MeshSolid;
+    if (nu < 3) nu = 3;
+    if (nv < 3) nv = 3;
+    for (int i = 0; i < nu; i++) {
+        double ph = 2.0 * D_PI * i / nu;
+        for (int j = 0; j < nv; j++) {
+            double th = 2.0 * D_PI * j / nv;
+            double R = 1.0 + r * cos(th);
+            m->AddVertex(R * cos(ph), R * sin(ph), r * sin(th));
+        }
+    }
+    for (int i = 0; i < nu; i++) {
+        int i1 = (i + 1) % nu;
+        for (int j = 0; j < nv; j++) {
+            int j1 = (j + 1) % nv;
+            int a = i * nv + j, b = i1 * nv + j, c = i1 * nv + j1, d = i * nv + j1;
+            m->AddTriangle(a, b, c);
+            m->AddTriangle(a, c, d);
+        }
+    }
+    return m;
+}
+MeshSolid *MeshIcosahedron()
+{
+    MeshSolid *m = new MeshSolid;
+    const double t = (1.0 + sqrt(5.0)) / 2.0, s = 1.0 / sqrt(1.0 + t * t);
+    const double P[12][3] = { {-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t}, {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1} };
+    for (int i = 0; i < 12; i++) m->AddVertex(P[i][0] * s, P[i][1] * s, P[i][2] * s);
+    static const int f[20][3] = { {0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4}, {11, 10, 2}, {10, 7, 6}, {7, 1, 8},
+                                  {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8}, {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1} };
+    for (int i = 0; i < 20; i++) m->AddTriangle(f[i][0], f[i][1], f[i][2]);
+    return m;
+}
 int AffineSolid::Emit(RtSerializer &s)
 {
     int i = s.add(RT_NODE_AFFINE, this);

@@ -285,6 +285,27 @@ struct Torus : Solid {
     int Emit(RtSerializer &s);
 };
 
+/* A closed triangle mesh as a Solid (policy Q14): vertices and triangles in the form ObjectFormat.cpp:12-28 holds them,
+   read by the grammar of LoadObjFile (:31-75: "v x y z" and "f a/b c/d e/f", plus plain "f a b c"; OBJ indices are
+   1-based), or made procedurally.  Winding: counter-clockwise seen from outside, so Cross(e1, e2) points out. */
+struct MeshSolid : Solid {
+    std::vector<double> rgfVertices;    /* x y z per vertex */
+    std::vector<int>    rgnTriangles;   /* iV0 iV1 iV2 per triangle, 0-based */
+    Extent e;
+    MeshSolid() {}
+    int  nVertices() const { return (int)(rgfVertices.size() / 3); }
+    int  nTriangles() const { return (int)(rgnTriangles.size() / 3); }
+    void AddVertex(double x, double y, double z);
+    void AddTriangle(int a, int b, int c) { rgnTriangles.push_back(a); rgnTriangles.push_back(b); rgnTriangles.push_back(c); }
+    int  LoadObjText(const char *sz);           /* returns the number of vertices read, 0 on a malformed face */
+    int  LoadObjFile(const char *szFile);
+    Extent GetExtent() { return e; }
+    int Emit(RtSerializer &s);
+};
+MeshSolid *MeshSphere(int nLongitude, int nLatitude);          /* unit sphere, 2 * nLongitude * (nLatitude - 1) triangles */
+MeshSolid *MeshTorus(int nMajor, int nMinor, double fMinorRadius);     /* same shape as Torus(r), 2 * nMajor * nMinor triangles */
+MeshSolid *MeshIcosahedron();                                   /* 20 triangles, vertices on the unit sphere */
+
 #define SURF_MATTE      RT_SURF_MATTE
 #define SURF_BURNISHED  RT_SURF_BURNISHED
 #define SURF_SMOOTH     RT_SURF_SMOOTH

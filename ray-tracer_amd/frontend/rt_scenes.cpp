@@ -286,6 +286,26 @@ struct Parser {
         else if (w == "slab") r = new Slab;
         else if (w == "torus") r = new Torus(num());
         else if (w == "null") r = new NullSolid;
+        else if (w == "meshsphere") { int a = (int)num(), b = (int)num(); r = MeshSphere(a, b); }
+        else if (w == "meshtorus") { int a = (int)num(), b = (int)num(); double c = num(); r = MeshTorus(a, b, c); }
+        else if (w == "meshicosahedron") r = MeshIcosahedron();
+        else if (w == "mesh") {                 /* (mesh nVertices nTriangles  x y z ...  a b c ...) with 0-based indices */
+            int nv = (int)num(), nt = (int)num();
+            MeshSolid *m = new MeshSolid;
+            for (int k = 0; k < nv && err.empty(); k++) { double x = num(), y = num(), z = num(); m->AddVertex(x, y, z); }
+            for (int k = 0; k < nt && err.empty(); k++) {
+                int a = (int)num(), b = (int)num(), c = (int)num();
+                if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) { fail("mesh index out of range"); break; }
+                m->AddTriangle(a, b, c);
+            }
+            r = m;
+        }
+        else if (w == "objfile") {              /* (objfile path): the grammar of LoadObjFile, ObjectFormat.cpp:31-75 */
+            std::string path = word();
+            MeshSolid *m = new MeshSolid;
+            if (!m->LoadObjFile(path.c_str())) fail("cannot read OBJ file " + path);
+            r = m;
+        }
         else if (w == "translate") { double x = num(), y = num(), z = num(); r = new Translate(x, y, z, solid()); }
         else if (w == "scale") { double x = num(), y = num(), z = num(); r = new Scale(x, y, z, solid()); }
         else if (w == "rotate") { double x = num(), y = num(), z = num(); r = new Rotate(x, y, z, solid()); }

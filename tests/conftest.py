@@ -135,6 +135,25 @@ SCENE_COLOUR = """(scene
 
 
 # Foggy propagator (TextureMaps.cpp:39-57) around and inside glass, seen through each of the other two cameras
+MESH_CUBE = ("(mesh 8 12  -1 -1 -1  1 -1 -1  1 1 -1  -1 1 -1  -1 -1 1  1 -1 1  1 1 1  -1 1 1 "
+             "  0 2 1  0 3 2  4 5 6  4 6 7  0 1 5  0 5 4  3 6 2  3 7 6  0 4 7  0 7 3  1 2 6  1 6 5)")
+
+# closed triangle meshes as Solids (policy Q14) in every CSG position; no torus and no exp(), so the device must be bit exact
+SCENE_MESH = """(scene
+ (model (union
+   (surface burnished none (makeunion
+     (translate -2 -1.6 0 (material 0.9 auto g_sRed metal none none (difference %s (scale 0.5 0.5 1.2 (cylinder)))))
+     (translate 2 -1.6 0 (rotate 0.3 0.2 0 (material 0.5 auto g_sGreen plastic none none (intersection (meshicosahedron) (scale 0.9 0.9 0.9 (sphere))))))
+     (translate -2 1.6 0 (rotate 0.9 0.3 0 (material 0.9 auto g_sYellow metal none none (meshtorus 24 12 0.35))))
+     (translate 2 1.6 0 (material 0.9 1.5 g_sWhite transparent none none (surface polished none (meshsphere 16 9))))
+     (scale 0.8 0.8 0.8 (material 0.9 auto g_sCyan plastic none none (union (meshsphere 12 7) (translate 0.7 0 0 (meshicosahedron)))))))
+   (translate 0 4 -6 (scale 12 1 12 (cube)))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 10 -10 10 (scale (blackbody 6500) 10000))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 800))
+ (camera stereographic 0 0 9 70)
+ (sampler fastblue))""" % MESH_CUBE
+
 SCENE_FOG_PERSPECTIVE = """(scene
  (model (makeunion
    (translate 0 0 -1 (scale 4 4 4 (material 0.2 1.0 (scale g_sEqualWhite 0.002) transparent none foggy (surface polished none (sphere)))))

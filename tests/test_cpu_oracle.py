@@ -298,3 +298,79 @@ def test_solid_colour_textures_restatement(rt, oracle):
         plain = plain.replace(" %s none " % name, " none none ").replace(" %s coloredglass " % name, " none coloredglass ")
     c = img(plain)
     assert (np.abs(a - c).max(axis=0) > 1e-4).mean() > 0.3
+
+
+def _mesh_arrays(fs):
+    d = fs.desc.contents
+    for i in range(d.n_nodes):
+        nd = d.nodes[i]
+        if nd.type == 15:       # RT_NODE_MESH
+            arr = np.ctypeslib.as_array(d.data, shape=(nd.data + nd.ndata,))[nd.data:nd.data + nd.ndata].copy()
+            return arr[:3 * nd.i0].reshape(-1, 3), arr[3 * nd.i0:].reshape(-1, 3).astype(int)
+    raise AssertionError("no mesh node")
+
+
+@pytest.mark.parametrize("body", ["(meshicosahedron)", "(meshsphere 16 9)", "(meshsphere 3 2)", "(meshtorus 24 12 0.35)"])
+def test_mesh_generators_make_closed_outward_meshes(rt, body):
+    """Policy Q14 asks for closed meshes wound counter-clockwise seen from outside: every directed edge once, its reverse
+    once, positive signed volume."""
+    fs = rt.FrontScene("(scene (model %s))" % body, "test", optimize=True)
+    v, f = _mesh_arrays(fs)
+    edges = {}
+    for a, b, c in f:
+        for e in ((a, b), (b, c), (c, a)):
+            edges[e] = edges.get(e, 0) + 1
+    assert all(n == 1 for n in edges.values()) and all((y, x) in edges for (x, y) in edges)
+    assert sum(np.dot(v[a], np.cross(v[b], v[c])) for a, b, c in f) > 0
+
+
+def test_obj_grammar_of_LoadObjFile(rt, tmp_path):
+    """LoadObjFile's grammar (ObjectFormat.cpp:46-66): "v x y z" and "f a/b c/d e/f" (texture indices ignored), 1-based;
+    plain "f a b c" too; other lines skipped; a face naming a vertex that does not exist is an error."""
+    from conftest import MESH_CUBE
+    want_v, want_f = _mesh_arrays(rt.FrontScene("(scene (model %s))" % MESH_CUBE, "test"))
+    lines = ["# a cube", "o cube"] + ["v %r %r %r" % tuple(p) for p in want_v.tolist()] + ["vt 0 0"]
+    for k, (a, b, c) in enumerate(want_f):
+        lines.append("f %d/1 %d/1 %d/1" % (a + 1, b + 1, c + 1) if k % 2 else "f %d %d %d" % (a + 1, b + 1, c + 1))
+    path = tmp_path / "cube.obj"
+    path.write_text("\n".join(lines) + "\n")
+    v, f = _mesh_arrays(rt.FrontScene("(scene (model (objfile %s)))" % path, "test"))
+    assert np.array_equal(v, want_v) and np.array_equal(f, want_f)
+    L = rt.frontend_lib()
+    out = np.zeros(6)
+    assert L.rtf_extent(("(translate 0 3 0 (objfile %s))" % path).encode(), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert (out == [-1, 2, -1, 1, 4, 1]).all()
+    path.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n")
+    with pytest.raises(Exception):
+        rt.FrontScene("(scene (model (objfile %s)))" % path, "test")
+
+
+def test_mesh_solid_restatement_against_the_same_solid_made_of_planes(rt, oracle):
+    """Policy Q14 pinned on shapes the reference does have: a cube of twelve triangles must give the hit lists of Cube
+    (ConvexPolyhedron, Solids.cpp:660-760) from outside, from inside and inside a Difference -- same counts, materials and
+    surfaces, t to rounding, normals parallel -- and a finely tessellated sphere must approach Sphere."""
+    from conftest import MESH_CUBE
+    rng = np.random.default_rng(1)
+    n = 4000
+    dr = np.concatenate([rng.uniform(-0.4, 0.4, (n, 2)), -np.ones((n, 1))], axis=1)
+    outside = np.tile(np.array([0.3, 0.2, 6.0]), (n, 1)) + rng.normal(0, 0.05, (n, 3))
+    inside = rng.normal(0, 0.2, (n, 3))
+    wrap = "(material 0.9 auto g_sRed plastic none none (rotate 0.3 0.4 0.1 (difference %s (scale 0.5 0.5 1.2 (cylinder)))))"
+    for org in (outside, inside):
+        fa = rt.FrontScene("(scene (model %s))" % (wrap % MESH_CUBE), "test")
+        fb = rt.FrontScene("(scene (model %s))" % (wrap % "(cube)"), "test")
+        a = oracle.OracleScene(fa.desc).intersect(org, dr, max_hits=8, transform=1)
+        b = oracle.OracleScene(fb.desc).intersect(org, dr, max_hits=8, transform=1)
+        assert (b[0] > 0).mean() > 0.2
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+        assert np.allclose(a[1], b[1], rtol=0, atol=1e-12)
+        na = a[2] / np.maximum(1e-300, np.linalg.norm(a[2], axis=2, keepdims=True))
+        nb = b[2] / np.maximum(1e-300, np.linalg.norm(b[2], axis=2, keepdims=True))
+        assert np.allclose(na, nb, atol=1e-12)
+    fa = rt.FrontScene("(scene (model (meshsphere 256 128)))", "test")
+    fb = rt.FrontScene("(scene (model (sphere)))", "test")
+    a = oracle.OracleScene(fa.desc).intersect(outside[:400], dr[:400] * [0.4, 0.4, 1.0], max_hits=4)
+    b = oracle.OracleScene(fb.desc).intersect(outside[:400], dr[:400] * [0.4, 0.4, 1.0], max_hits=4)
+    both = (a[0] == 2) & (b[0] == 2)
+    assert both.sum() > 100 and (a[0] != b[0]).mean() < 0.02          # silhouette rays only
+    assert np.abs(a[1][both] - b[1][both]).max() < 5e-3

@@ -11,7 +11,7 @@ Bars:
 import numpy as np
 import pytest
 
-from conftest import SCENE_COLOUR, SCENE_FOG_ORTHOGRAPHIC, SCENE_FOG_PERSPECTIVE, SCENE_FRACTAL, SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
+from conftest import SCENE_MESH, SCENE_COLOUR, SCENE_FOG_ORTHOGRAPHIC, SCENE_FOG_PERSPECTIVE, SCENE_FRACTAL, SCENE_ROW, SCENE_BUMPY, SCENE_CSG, SCENE_GLASS
 
 pytestmark = pytest.mark.gpu
 
@@ -67,13 +67,13 @@ def _rays(rng, n, z=8.0, spread=0.7):
     return org, dr
 
 
-@pytest.mark.parametrize("scene,exact", [("S0", True), ("S2", True), ("S1", False), (SCENE_CSG, False)],
-                         ids=["S0", "S2", "S1", "CSG"])
+@pytest.mark.parametrize("scene,exact", [("S0", True), ("S2", True), ("S1", False), (SCENE_CSG, False), (SCENE_MESH, True)],
+                         ids=["S0", "S2", "S1", "CSG", "mesh"])
 def test_hit_lists_match_oracle(gpu, oracle, scene, exact):
     """a4-a10: full hit lists (count, t, primitive id, material id, surface id, object-space normal)."""
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
     rng = np.random.default_rng(7)
-    org, dr = _rays(rng, 30000, 9.0 if scene is SCENE_CSG else 8.0, 0.15 if scene == "S0" else 0.7)
+    org, dr = _rays(rng, 30000, 9.0 if scene in (SCENE_CSG, SCENE_MESH) else 8.0, 0.15 if scene == "S0" else 0.7)
     gc, gt, gn, gl, gm, gs = g.intersect(org, dr, max_hits=12)
     oc, ot, on, ol, om, osf = o.intersect(org, dr, max_hits=12)
     assert (oc > 0).mean() > 0.2
@@ -115,14 +115,14 @@ def test_transformed_normals_and_bump_noise(gpu, oracle, scene):
     assert np.array_equal(gn[notorus], on[notorus])
 
 
-@pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 1e-6), ("S2", 0.0), (SCENE_GLASS, 1e-6), (SCENE_BUMPY, 1e-6), (SCENE_CSG, 1e-6), (SCENE_FRACTAL, 1e-6)],
-                         ids=["S0", "S1", "S2", "glass", "bumpy", "csg", "fractal"])
+@pytest.mark.parametrize("scene,tol", [("S0", 0.0), ("S1", 1e-6), ("S2", 0.0), (SCENE_GLASS, 1e-6), (SCENE_BUMPY, 1e-6), (SCENE_CSG, 1e-6), (SCENE_FRACTAL, 1e-6), (SCENE_MESH, 0.0)],
+                         ids=["S0", "S1", "S2", "glass", "bumpy", "csg", "fractal", "mesh"])
 def test_radiance_matches_oracle(gpu, oracle, scene, tol):
     """a11-a16: RayTracer::VisualRay through the wavefront pipeline (shadow, reflection, refraction queues)."""
     opt, raw, g, o = _pair(gpu, oracle, scene, "test")
     rng = np.random.default_rng(11)
     n = 20000
-    org, dr = _rays(rng, n, 9.0 if scene in (SCENE_CSG, "S2") else 8.0, 0.15 if scene == "S0" else 0.6)
+    org, dr = _rays(rng, n, 9.0 if scene in (SCENE_CSG, SCENE_MESH, "S2") else 8.0, 0.15 if scene == "S0" else 0.6)
     aux = rng.uniform(-1, 1, (n, 6))
     a = g.radiance(org, dr, aux)
     b = o.radiance(org, dr, aux)
@@ -189,7 +189,8 @@ def test_solid_colour_textures(gpu, oracle):
     ("S1", "fastblue", 128, 128, 4, 1e-6),
     ("S2", "", 120, 72, 4, 0.0),
     (SCENE_GLASS, "", 96, 96, 4, 1e-5),
-], ids=["S0_test", "S0_fastblue16", "S1_fastblue4", "S2_dof", "glass"])
+    (SCENE_MESH, "", 96, 64, 4, 0.0),
+], ids=["S0_test", "S0_fastblue16", "S1_fastblue4", "S2_dof", "glass", "mesh"])
 def test_render_matches_oracle(gpu, oracle, scene, sampler, w, h, spp, tol):
     """a17-a18: RayTracer::Render end to end: sample count, ray counts and the linear-RGB image."""
     opt, raw, g, o = _pair(gpu, oracle, scene, sampler)
@@ -496,3 +497,53 @@ def test_foggy_propagator_and_render(gpu, oracle, scene):
     ref, _, n = o.render(64, 48, 4, rd, ost, threads=4)
     assert st.samples == n and st.rays() == ost.rays()
     assert np.abs(img - ref).max() < 2e-5 and ref.mean() > 1e-3
+
+
+def test_mesh_bvh_never_changes_hit_lists(gpu, oracle):
+    """a19 (policy Q14): the oracle tests every triangle, the device walks the mesh's BVH (deep here: 100k triangles)
+    and may only skip triangles the ray misses.  Hit lists of random rays, origins outside and inside, bit exact."""
+    spec = "(scene (model (rotate 0.4 0.3 0.2 (union (material 0.9 auto g_sRed plastic none none (meshsphere 250 100)) (translate 1.3 0 0 (meshtorus 300 84 0.4))))))"
+    opt, raw, g, o = _pair(gpu, oracle, spec, "test")
+    rng = np.random.default_rng(23)
+    n = 3000
+    org, dr = _rays(rng, n, 6.0, 0.45)
+    org[n // 2:] = rng.normal(0, 0.3, (n - n // 2, 3))                  # inside the sphere
+    dr[n // 2:] = rng.normal(0, 1, (n - n // 2, 3))
+    gr = g.intersect(org, dr, max_hits=10)
+    orr = o.intersect(org, dr, max_hits=10)
+    assert (orr[0] > 0).mean() > 0.6 and orr[0].max() >= 4
+    for x, y in zip(gr, orr):
+        assert np.array_equal(x, y)
+
+
+def test_obj_file_renders_like_the_same_mesh_inline(gpu, tmp_path):
+    """8(b) LoadObjFile's grammar in front of the device path: an OBJ written from the generated torus renders the same
+    frame as the generated torus."""
+    body = "(meshtorus 20 10 0.4)"
+    fs = gpu.FrontScene("(scene (model (rotate 1.0 0.2 0 (material 0.9 auto g_sGold metal none none %s))) (pointlight -10 -10 10 (scale (blackbody 6500) 2000)) (camera perspective 0 0 6 40))" % body, "fastblue")
+    d = fs.desc.contents
+    nd = [d.nodes[i] for i in range(d.n_nodes) if d.nodes[i].type == 15][0]
+    arr = np.ctypeslib.as_array(d.data, shape=(nd.data + nd.ndata,))[nd.data:nd.data + nd.ndata]
+    v, f = arr[:3 * nd.i0].reshape(-1, 3), arr[3 * nd.i0:].reshape(-1, 3).astype(int)
+    L = ["v %r %r %r" % tuple(p) for p in v.tolist()] + ["f %d/1 %d/1 %d/1" % (a + 1, b + 1, c + 1) for a, b, c in f]
+    path = tmp_path / "torus.obj"
+    path.write_text("\n".join(L) + "\n")
+    fo = gpu.FrontScene("(scene (model (rotate 1.0 0.2 0 (material 0.9 auto g_sGold metal none none (objfile %s)))) (pointlight -10 -10 10 (scale (blackbody 6500) 2000)) (camera perspective 0 0 6 40))" % path, "fastblue")
+    a, sa = gpu.GpuScene(fs.desc).render(96, 64, 4)
+    b, sb = gpu.GpuScene(fo.desc).render(96, 64, 4)
+    assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0
+
+
+def test_mesh_at_scale_converges_to_the_quadric(gpu):
+    """a19 at BASELINE config[3]'s order of size (here 2.4 M triangles; bench.py --workload mesh runs 10 M): no golden
+    image can exist, so a property: a sphere of that many triangles must render like Sphere itself (same scene, same
+    samples), no hit list may overflow, and the ray counts must agree to silhouette rays."""
+    rest = "(translate 0 2.2 -1 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube)))))) (ambient (scale (blackbody 6500) 0.02)) (pointlight -10 -10 10 (scale (blackbody 6500) 2000)) (camera perspective 0 0 6 45)"
+    spec = "(scene (model (union (material 0.9 auto g_sRed plastic none none (surface shiny none %s)) " + rest + ")"
+    fm = gpu.FrontScene(spec % "(meshsphere 1600 750)", "fastblue")
+    fq = gpu.FrontScene(spec % "(sphere)", "fastblue")
+    a, sa = gpu.GpuScene(fm.desc).render(256, 192, 4)
+    b, sb = gpu.GpuScene(fq.desc).render(256, 192, 4)
+    assert sa.hit_overflow == 0 and sa.samples == sb.samples
+    assert abs(sa.rays() - sb.rays()) <= 2e-3 * sb.rays()
+    assert _rel_rmse(a, b) < 2e-2 and np.abs(a - b).mean() < 1e-3 * b.mean() + 1e-4
