@@ -33,6 +33,19 @@ HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic_k_visual.json")
 
 
+# BASELINE configs[3]: a synthetic mesh of about ten million triangles (a lobed, star-shaped closed surface of
+# 2 * 3200 * 1562 = 9,996,800 triangles) on a floor, one area light and one point light: every ray walks the mesh's BVH
+MESH_SCENE = """(scene
+ (model (union
+   (rotate 0.5 0.3 0 (material 0.9 auto g_sOrange plastic none none (surface shiny none (meshblob %d %d 0.08 5))))
+   (translate 0 1.6 -1 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 9 -6.5 12 (scale (blackbody 6500) 8000))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 2000))
+ (camera perspective 0 0 6 40))"""
+NAMED_SCENES = {"MESH10M": MESH_SCENE % (3200, 1563), "MESH1M": MESH_SCENE % (1000, 501), "MESH100K": MESH_SCENE % (320, 157)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +80,8 @@ def main():
         if rt.rt_lib().rt_set_option(name.encode(), int(val)):
             raise SystemExit("bad --opts entry %r" % kv)
     W, H, spp = args.width, args.height, args.spp
+    scene_name = args.scene
+    args.scene = NAMED_SCENES.get(scene_name, scene_name)
     fs = rt.FrontScene(args.scene, "fastblue", optimize=True)
     gs = rt.GpuScene(fs.desc)
     # contiguous row bands; every rank traces its own halo, so the data path has no exchange
@@ -125,14 +140,14 @@ def main():
             "metric": "rays/sec (primary+secondary)", "value": rays_all / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64)" % (args.scene, W, H, spp),
-                       "scene": args.scene, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
+            "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64, configs[3] when MESH10M)" % (scene_name, W, H, spp),
+                       "scene": scene_name, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
                        "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows},
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene)
+            res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene, scene_name)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
@@ -190,13 +205,18 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total, workload):
                                "shaded_boundaries": boundaries / m, "light_terms": lights / m}}
 
 
-def cpu_baseline(ge, rt, scene):
+def cpu_baseline(ge, rt, scene, name):
     """The oracle (CPU port of the reference's algorithm, oracle/) timed on this host: a bounded sample of the
-    same workload -- the same scene and sampler at 256x144, 16 spp (same rays per sample) -- on 1 thread."""
+    same workload -- the same scene and sampler at 256x144, 16 spp (same rays per sample) -- on 1 thread.
+    For the mesh workloads the oracle tests every triangle per ray (the reference has no hierarchy over triangles
+    either: ObjectFormat.cpp holds flat arrays), so the sample is a few hundred rays."""
     ob = ge.load_oracle()
     raw = rt.FrontScene(scene, "fastblue", optimize=False)
     osc = ob.OracleScene(raw.desc)
-    w, h, spp = (512, 288, 16) if scene == "S0" else (640, 360, 16)     # about 15-25 s of single-thread work
+    w, h, spp = (512, 288, 16) if name == "S0" else (640, 360, 16)     # about 15-25 s of single-thread work
+    if name.startswith("MESH"):
+        w, h, spp = {"MESH10M": (12, 8, 1), "MESH1M": (40, 24, 1)}.get(name, (80, 48, 1))
+    scene = name
     rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
     st = rt.RtStats()
     t0 = time.perf_counter()

@@ -121,6 +121,9 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    next to the chain records when they fit; takes effect at rt_scene_upload),
    "tile_mask" (0/1: a pre-pass marks the sampling tiles no ray of which can touch a box of the scene; their samples end
    without being generated),
+   "full_waves" (1 / 2, default 2: waves per SIMD the kernels for the rare features -- tori, meshes, textures,
+   propagators, spectral metals -- are built for; two hide the latency of mesh walks, one has no register spills; at
+   rt_scene_upload),
    "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */
 int  rt_set_option(const char *name, int64_t value);
 

@@ -563,7 +563,8 @@ RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena 
  * test in the form of ObjectFormat.cpp:79-102, with its two slips put right (the second barycentric test is
  * u + v > 1, and t = f * Dot(e2, q)) and its parallel test made scale free (|cos| < EPSILON instead of |a| < EPSILON,
  * which would delete every triangle of a fine mesh).  Crossings ahead of the origin (t >= 0) are gathered through the
- * mesh's BVH, the RT_MESH_MAXHITS nearest kept in (t, triangle) order, and handed to HitList as any solver's roots
+ * mesh's BVH, the RT_MESH_MAXHITS nearest kept (MAXHITS of Solids.h:20; more is not an error here, the oracle keeps
+ * the same ones) in (t, triangle) order, and handed to HitList as any solver's roots
  * are; an odd number of them means the origin is inside, which HitList is told by one root behind the origin. */
 struct MeshWork {
     double r[RT_MESH_MAXHITS + 3];
@@ -589,63 +590,101 @@ RT_DEV bool mesh_triangle(const RtMeshTri &T, const DRay &ray, double &t)
     t = f * dot(e2, q);
     return t >= 0.0;
 }
-RT_DEV bool mesh_box_hit(const RtMeshNode &nd, const DRay &ray)
+#ifdef RT_MESH_COUNT        /* instrumentation build (RT_EXTRA_DEFS=-DRT_MESH_COUNT): [0] rays, [1] node visits, [2] leaf visits, [3] triangle tests, [4] wave-iterations of the node loop, [5] of the leaf loop */
+__device__ unsigned long long g_mesh_count[8];
+#define MESH_COUNT(k, v) atomicAdd(&g_mesh_count[k], (unsigned long long)(v))
+#else
+#define MESH_COUNT(k, v)
+#endif
+struct MeshRay { double o[3], inv[3]; int par[3]; };      /* par: the direction component is zero */
+RT_DEV bool mesh_slot_hit(const RtMeshNode &nd, int k, const MeshRay &mr)
 {
     double t0 = 0.0, t1 = RT_INFINITY;
-    const double o[3] = { ray.org.x, ray.org.y, ray.org.z }, d[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+    bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const double lo = (double)nd.lo[k], hi = (double)nd.hi[k];
-        if (d[k] != 0.0) {
-            const double inv = 1.0 / d[k];
-            double ta = (lo - o[k]) * inv, tb = (hi - o[k]) * inv;
-            if (ta > tb) { const double x = ta; ta = tb; tb = x; }
-            /* one part in 1e9 of slack on top of the padded boxes: the division above is not the arithmetic of the triangle test */
-            ta -= fabs(ta) * 1e-9; tb += fabs(tb) * 1e-9;
-            if (ta > t0) t0 = ta;
-            if (tb < t1) t1 = tb;
-        } else if (o[k] < lo || o[k] > hi) return false;
+    for (int a = 0; a < 3; a++) {
+        const double lo = (double)nd.lo[a][k], hi = (double)nd.hi[a][k];
+        if (!mr.par[a]) {
+            double ta = (lo - mr.o[a]) * mr.inv[a], tb = (hi - mr.o[a]) * mr.inv[a];
+            const double tn = fmin(ta, tb), tf = fmax(ta, tb);
+            /* one part in 1e9 of slack on top of the padded boxes: this is not the arithmetic of the triangle test */
+            t0 = fmax(t0, tn - fabs(tn) * 1e-9);
+            t1 = fmin(t1, tf + fabs(tf) * 1e-9);
+        } else ok = ok && !(mr.o[a] < lo || mr.o[a] > hi);
     }
-    return t0 <= t1;
+    return ok && t0 <= t1;
 }
-RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag)
+RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag, int *lds_stack, int lds_stride)
 {
+    /* the traversal stack lives in LDS, one column per lane (entry i at [i * stride + lane]: no bank conflicts): in
+       private memory every push and pop is a round trip through the vector memory path, which then is the clock of
+       the whole walk */
+    int *const stack = lds_stack + threadIdx.x;
+#define MSTK(i) stack[(i) * lds_stride]
     const RtMeshInfo mi = S.meshes[mp.plane0];
     const RtMeshNode *nodes = S.mesh_nodes + mi.node0;
     const RtMeshTri *tris = S.mesh_tris + mi.tri0;
+    MeshRay mr;
+    mr.o[0] = ray.org.x; mr.o[1] = ray.org.y; mr.o[2] = ray.org.z;
+    {
+        const double d[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+#pragma unroll
+        for (int a = 0; a < 3; a++) { mr.par[a] = d[a] == 0.0; mr.inv[a] = mr.par[a] ? 0.0 : 1.0 / d[a]; }
+    }
     double ht[RT_MESH_MAXHITS];
     int    hq[RT_MESH_MAXHITS];         /* position in tris[] */
     int    nh = 0, total = 0;
-    int    stack[RT_MESH_STACK];
     int    sp = 0;
-    stack[sp++] = 0;
+    /* One loop: pop a node, test its four boxes, push the inner children that are hit, and test the triangles of the
+       leaf slots that are hit through one bit mask (bit 4k + i = triangle i of slot k), so that a wave runs the
+       triangle test as many times as its busiest lane has triangles, not once per slot and position.  Crossings are
+       appended unsorted (stores do not stall; a sorted insert would load from private memory in the loop) and put
+       in (t, triangle) order once, after the walk. */
+    MSTK(sp) = 0; sp++;
+    MESH_COUNT(0, 1);
     while (sp > 0) {
-        const RtMeshNode nd = nodes[stack[--sp]];
-        if (!mesh_box_hit(nd, ray)) continue;
-        if (nd.a >= 0) {
-            if (sp + 2 > RT_MESH_STACK) { A.overflow = 1; break; }
-            stack[sp++] = nd.b;
-            stack[sp++] = nd.a;
-            continue;
+        const RtMeshNode &nd = nodes[MSTK(--sp)];
+        MESH_COUNT(1, 1);
+        bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
+        if (sp + 4 > RT_MESH_STACK) { A.overflow = 1; break; }
+        unsigned mask = 0;
+        int c4[4];
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            c4[k] = nd.child[k];
+            if (!hit[k]) continue;
+            if (c4[k] >= 0) { MSTK(sp) = c4[k]; sp++; }
+            else mask |= ((1u << nd.count[k]) - 1u) << (4 * k);
         }
-        const int first = ~nd.a;
-        for (int q = first; q < first + nd.b; q++) {
+        while (mask) {
+            const int b = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int k = b >> 2;
+            const int q = ~(k == 0 ? c4[0] : k == 1 ? c4[1] : k == 2 ? c4[2] : c4[3]) + (b & 3);
+            MESH_COUNT(3, 1);
             double t;
             if (!mesh_triangle(tris[q], ray, t)) continue;
+            if (nh < RT_MESH_MAXHITS) { ht[nh] = t; hq[nh] = q; nh++; }
+            else {          /* rare (a ray skimming a faceted saddle): keep the RT_MESH_MAXHITS nearest, as the oracle does */
+                int m = 0;
+                for (int i = 1; i < RT_MESH_MAXHITS; i++)
+                    if (ht[i] > ht[m] || (ht[i] == ht[m] && tris[hq[i]].id > tris[hq[m]].id)) m = i;
+                if (t < ht[m] || (t == ht[m] && tris[q].id < tris[hq[m]].id)) { ht[m] = t; hq[m] = q; }
+            }
             total++;
-            const int id = tris[q].id;
-            /* insert into the sorted nearest-RT_MESH_MAXHITS set, order (t, triangle id) */
-            int j = nh;
-            if (nh == RT_MESH_MAXHITS) {
-                const int l = nh - 1;
-                if (t > ht[l] || (t == ht[l] && id > tris[hq[l]].id)) continue;
-                j = l;
-            } else nh++;
-            for (; j > 0 && (t < ht[j - 1] || (t == ht[j - 1] && id < tris[hq[j - 1]].id)); --j) { ht[j] = ht[j - 1]; hq[j] = hq[j - 1]; }
-            ht[j] = t; hq[j] = q;
         }
     }
-    if (total > RT_MESH_MAXHITS) A.overflow = 1;
+    /* insertion sort, order (t, triangle id) */
+    for (int i = 1; i < nh; i++) {
+        const double t = ht[i];
+        const int q = hq[i], id = tris[q].id;
+        int j = i;
+        for (; j > 0 && (t < ht[j - 1] || (t == ht[j - 1] && id < tris[hq[j - 1]].id)); --j) { ht[j] = ht[j - 1]; hq[j] = hq[j - 1]; }
+        ht[j] = t; hq[j] = q;
+    }
+    (void)total;
     if (nh == 0) return;
     MeshWork w;
     w.inside_inf = 0; w.eps = RT_EPSILON;
@@ -658,6 +697,7 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
     }
     w.count = nh + behind;
     hit_list(w, A, tag, prim, mp.leaf_affine);
+#undef MSTK
 }
 
 /* ================================================================== CSG merge (Solids.cpp:987-1058) */
@@ -750,7 +790,7 @@ RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
 /* workgroup-shared staging in dynamic LDS: the first n_nodes nodes of the scene's BVH, the scene's chain records
    (persistent kernels, when they all fit), then the per-lane traversal stacks (RT_BVH_STACK x blockDim.x x 2 B).
    The host sizes the allocation (rt_scene_upload: lds_small / lds_visual / lds_shadow). */
-struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int n_nodes, n_chains, stride; };
+struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int *mstack; int n_nodes, n_chains, stride; };
 #define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * (L).stride + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
 /* 8-byte words of LDS the small scene tables take when staged (same arithmetic on the host: rt_scene_upload) */
@@ -798,6 +838,7 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds, RtDevScene
         SL->region_lca = lds_stage(cur, S.region_lca, S.n_lca);
     }
     L.stack = (uint16_t *)cur;
+    L.mstack = (int *)(L.stack + RT_BVH_STACK * blockDim.x);    /* present only when the launch was sized for it: scenes with meshes, FULL kernels */
     __syncthreads();
     return L;
 }
@@ -952,7 +993,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MESH:
             if constexpr (LITE) { A.bail = 1; goto done; }
-            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L.mstack, L.stride); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -1050,7 +1091,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 default:
                     if constexpr (LITE) { A.bail = 1; goto done; }
                     else {
-                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag);
+                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag, L.mstack, L.stride);
                         else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }

@@ -157,15 +157,18 @@ typedef struct RtChain {
     int32_t wrap_tex[RT_CHAIN_WRAPS];   /* texture call-out the wrapper queues, -1 none */
 } RtChain;
 
-/* Triangle meshes (policy Q14).  One binary BVH per mesh over its triangles, in the mesh's own frame; boxes are floats
-   rounded outward (one 32-byte node per load), triangles are stored in leaf order as (v0, e1, e2) with the edges
-   subtracted once on the host -- ObjectFormat.cpp:85-86 subtracts them per test, same doubles either way. */
+/* Triangle meshes (policy Q14).  One 4-wide BVH per mesh over its triangles, in the mesh's own frame: a node is one
+   128-byte line holding four child boxes (floats rounded outward) that are tested together -- half the dependent loads
+   of a binary tree, and the four slab tests are independent arithmetic.  Triangles are stored in leaf order as
+   (v0, e1, e2) with the edges subtracted once on the host -- ObjectFormat.cpp:85-86 subtracts them per test, same
+   doubles either way. */
 #define RT_MESH_MAXHITS 16          /* MAXHITS, Solids.h:20: crossings kept per ray and mesh (the nearest ones) */
-#define RT_MESH_STACK   64          /* pending BVH nodes per ray */
+#define RT_MESH_STACK   48          /* pending BVH entries per ray (LDS, 4 B each): 3 per level + 1, 2^27 triangles = 13 levels */
 #define RT_MESH_LEAF    4           /* triangles per leaf at most */
-typedef struct RtMeshNode {
-    float   lo[3], hi[3];
-    int32_t a, b;           /* inner: a, b = children (node indices relative to the mesh's first node); leaf: a = ~(first triangle), b = count */
+typedef struct __attribute__((aligned(128))) RtMeshNode {
+    float   lo[3][4], hi[3][4];
+    int32_t child[4];       /* >= 0: node index relative to the mesh's first node; < 0: leaf, first triangle = ~child */
+    int32_t count[4];       /* leaf: triangles (0 = unused slot) */
 } RtMeshNode;
 typedef struct RtMeshTri {
     double  v0[3], e1[3], e2[3];

@@ -220,7 +220,8 @@ struct Flattener {
         o.prims.push_back(pr);
         return (int)o.prims.size() - 1;
     }
-    /* binary BVH over the triangles of mesh node i: median split of the centroids along the widest axis */
+    /* 4-wide BVH over the triangles of mesh node i: the range is halved at the median of the centroids along its
+       widest axis, and each half again, which gives the four children of a node */
     struct MeshBuild {
         const double *v; const double *f;
         std::vector<int> order;
@@ -235,42 +236,67 @@ struct Flattener {
                 for (int k = 0; k < 3; k++) { if (q[k] < lo[k]) lo[k] = q[k]; if (q[k] > hi[k]) hi[k] = q[k]; }
             }
         }
-        int build(int first, int count)
+        void split(int first, int count, int &half)
         {
-            const int me = (int)(nodes->size() - node0);
-            nodes->push_back(RtMeshNode());
-            double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
             float clo[3] = { 3e38f, 3e38f, 3e38f }, chi[3] = { -3e38f, -3e38f, -3e38f };
-            for (int q = first; q < first + count; q++) {
-                double a[3], b[3];
-                tri_box(order[q], a, b);
+            for (int q = first; q < first + count; q++)
                 for (int k = 0; k < 3; k++) {
-                    if (a[k] < lo[k]) lo[k] = a[k];
-                    if (b[k] > hi[k]) hi[k] = b[k];
                     float c = cen[3 * (size_t)order[q] + k];
                     if (c < clo[k]) clo[k] = c;
                     if (c > chi[k]) chi[k] = c;
                 }
+            int ax = 0;
+            if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+            if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+            half = count / 2;
+            const std::vector<float> &C = cen;
+            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
+                             [&C, ax](int x, int y) { float cx = C[3 * (size_t)x + ax], cy = C[3 * (size_t)y + ax]; return cx < cy || (cx == cy && x < y); });
+        }
+        void range_box(int first, int count, RtMeshNode &nd, int slot) const
+        {
+            double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+            for (int q = first; q < first + count; q++) {
+                double a[3], b[3];
+                tri_box(order[q], a, b);
+                for (int k = 0; k < 3; k++) { if (a[k] < lo[k]) lo[k] = a[k]; if (b[k] > hi[k]) hi[k] = b[k]; }
             }
-            RtMeshNode nd;
             for (int k = 0; k < 3; k++) {       /* outward: a relative pad, then the float on the far side */
                 double e = 1e-6 * (hi[k] - lo[k]) + 1e-7 * (fabs(lo[k]) + fabs(hi[k])) + 1e-12;
                 float l = (float)(lo[k] - e), h = (float)(hi[k] + e);
                 if ((double)l > lo[k] - e) l = nextafterf(l, -INFINITY);
                 if ((double)h < hi[k] + e) h = nextafterf(h, INFINITY);
-                nd.lo[k] = l; nd.hi[k] = h;
+                nd.lo[k][slot] = l; nd.hi[k][slot] = h;
             }
-            if (count <= RT_MESH_LEAF) { nd.a = ~first; nd.b = count; (*nodes)[node0 + me] = nd; return me; }
-            int ax = 0;
-            if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
-            if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
-            const int half = count / 2;
-            const std::vector<float> &C = cen;
-            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
-                             [&C, ax](int x, int y) { float cx = C[3 * (size_t)x + ax], cy = C[3 * (size_t)y + ax]; return cx < cy || (cx == cy && x < y); });
-            int l = build(first, half);
-            int r = build(first + half, count - half);
-            nd.a = l; nd.b = r;
+        }
+        int build(int first, int count)
+        {
+            const int me = (int)(nodes->size() - node0);
+            nodes->push_back(RtMeshNode());
+            RtMeshNode nd;
+            memset(&nd, 0, sizeof nd);
+            for (int k = 0; k < 4; k++) { nd.child[k] = -1; nd.count[k] = 0; for (int a = 0; a < 3; a++) { nd.lo[a][k] = 1.0f; nd.hi[a][k] = -1.0f; } }
+            int r0[4], rc[4], nr = 0;
+            if (count <= RT_MESH_LEAF) { r0[0] = first; rc[0] = count; nr = 1; }
+            else {
+                int h;
+                split(first, count, h);
+                const int part0[2] = { first, first + h }, partc[2] = { h, count - h };
+                for (int s = 0; s < 2; s++) {
+                    if (partc[s] <= RT_MESH_LEAF) { r0[nr] = part0[s]; rc[nr] = partc[s]; nr++; }
+                    else {
+                        int h2;
+                        split(part0[s], partc[s], h2);
+                        r0[nr] = part0[s]; rc[nr] = h2; nr++;
+                        r0[nr] = part0[s] + h2; rc[nr] = partc[s] - h2; nr++;
+                    }
+                }
+            }
+            for (int k = 0; k < nr; k++) {
+                range_box(r0[k], rc[k], nd, k);
+                if (rc[k] <= RT_MESH_LEAF) { nd.child[k] = ~r0[k]; nd.count[k] = rc[k]; }
+                else { nd.child[k] = build(r0[k], rc[k]); nd.count[k] = 0; }
+            }
             (*nodes)[node0 + me] = nd;
             return me;
         }
@@ -280,6 +306,7 @@ struct Flattener {
         const RtNode &n = N(i);
         const double *p = D(i);
         const int nv = n.i0, nt = n.i1;
+        if (nt > (1 << 27)) { fail(RT_ERR_UNSUPPORTED, "mesh of more than 2^27 triangles"); return -1; }
         if (nv < 3 || nt < 1 || n.ndata != 3 * nv + 3 * nt) { fail(RT_ERR_INVALID, "mesh node with inconsistent sizes"); return -1; }
         const double *f = p + 3 * (size_t)nv;
         for (size_t k = 0; k < 3 * (size_t)nt; k++)

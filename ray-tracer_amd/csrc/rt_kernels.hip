@@ -391,8 +391,8 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 #define RT_LITE_SHADOW_THREADS 256
 #define RT_LITE_VISUAL_PER_CU  3
 #define RT_LITE_SHADOW_PER_CU  4
-#define RT_LB_VISUAL(LITE) __launch_bounds__(256, (LITE) ? 3 : 1)
-#define RT_LB_SHADOW(LITE) __launch_bounds__(256, (LITE) ? 4 : 1)
+#define RT_LB_VISUAL(LITE, MODE) __launch_bounds__(256, (LITE) ? 3 : ((MODE) < 0 ? 1 : 2))
+#define RT_LB_SHADOW(LITE, MODE) __launch_bounds__(256, (LITE) ? 4 : ((MODE) < 0 ? 1 : 2))
 #else
 #ifndef RT_LITE_VISUAL_THREADS
 #define RT_LITE_VISUAL_THREADS 768
@@ -402,8 +402,11 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 #endif
 #define RT_LITE_VISUAL_PER_CU  1
 #define RT_LITE_SHADOW_PER_CU  1
-#define RT_LB_VISUAL(LITE) __launch_bounds__((LITE) ? RT_LITE_VISUAL_THREADS : 256)
-#define RT_LB_SHADOW(LITE) __launch_bounds__((LITE) ? RT_LITE_SHADOW_THREADS : 256)
+/* FULL kernels come in two register budgets.  MODE 0 (default): 256 registers = two waves per SIMD (two workgroups of
+   256 per CU): mesh walks wait on memory and run 1.4x faster with a second wave to switch to; S2 458 ms against 472,
+   S1 the same.  MODE -1 (option full_waves = 1): the whole register file, one wave per SIMD, no spills. */
+#define RT_LB_VISUAL(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_VISUAL_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : 2)
+#define RT_LB_SHADOW(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_SHADOW_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : 2)
 #endif
 /* ------------------------------------------------------------------ k_visual
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
@@ -412,7 +415,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 /* MODE: what the workgroup stages in LDS besides the top of the BVH -- 0 nothing, 1 the chain records, 2 the chain records
    and the small scene tables (scene_lds_load); chosen per scene at upload, compiled in so that the loads are LDS loads */
 template <bool LITE, int MODE>
-__global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
+__global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;
@@ -615,7 +618,7 @@ __global__ void RT_LB_VISUAL(LITE) k_visual(const RtDevScene Sv, RtPipe P, int f
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
 template <bool LITE, int MODE>
-__global__ void RT_LB_SHADOW(LITE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
+__global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;

@@ -608,7 +608,8 @@ int MeshSolid::Emit(RtSerializer &s)
     s.nodes[i].i0 = nVertices(); s.nodes[i].i1 = nTriangles();
     return i;
 }
-MeshSolid *MeshSphere(int nu, int nv)
+MeshSolid *MeshSphere(int nu, int nv) { return MeshBlob(nu, nv, 0.0, 0); }
+MeshSolid *MeshBlob(int nu, int nv, double amp, int k)
 {
     MeshSolid *m = new MeshSolid;
     if (nu < 3) nu = 3;
@@ -618,7 +619,8 @@ MeshSolid *MeshSphere(int nu, int nv)
         double th = D_PI * j / nv;
         for (int i = 0; i < nu; i++) {
             double ph = 2.0 * D_PI * i / nu;
-            m->AddVertex(sin(th) * cos(ph), sin(th) * sin(ph), cos(th));
+            const double r = (amp != 0.0) ? 1.0 + amp * sin(k * ph) * sin(k * th) : 1.0;
+            m->AddVertex(r * (sin(th) * cos(ph)), r * (sin(th) * sin(ph)), r * cos(th));
         }
     }
     m->AddVertex(0.0, 0.0, -1.0);                              /* south pole */

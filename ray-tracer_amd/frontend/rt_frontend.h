@@ -303,6 +303,7 @@ struct MeshSolid : Solid {
     int Emit(RtSerializer &s);
 };
 MeshSolid *MeshSphere(int nLongitude, int nLatitude);          /* unit sphere, 2 * nLongitude * (nLatitude - 1) triangles */
+MeshSolid *MeshBlob(int nLongitude, int nLatitude, double fAmplitude, int nLobes);   /* star-shaped: radius 1 + a sin(k phi) sin(k theta) */
 MeshSolid *MeshTorus(int nMajor, int nMinor, double fMinorRadius);     /* same shape as Torus(r), 2 * nMajor * nMinor triangles */
 MeshSolid *MeshIcosahedron();                                   /* 20 triangles, vertices on the unit sphere */
 

@@ -287,6 +287,7 @@ struct Parser {
         else if (w == "torus") r = new Torus(num());
         else if (w == "null") r = new NullSolid;
         else if (w == "meshsphere") { int a = (int)num(), b = (int)num(); r = MeshSphere(a, b); }
+        else if (w == "meshblob") { int a = (int)num(), b = (int)num(); double c = num(); int k = (int)num(); r = MeshBlob(a, b, c, k); }
         else if (w == "meshtorus") { int a = (int)num(), b = (int)num(); double c = num(); r = MeshTorus(a, b, c); }
         else if (w == "meshicosahedron") r = MeshIcosahedron();
         else if (w == "mesh") {                 /* (mesh nVertices nTriangles  x y z ...  a b c ...) with 0-based indices */
