@@ -46,6 +46,15 @@ MESH_SCENE = """(scene
 NAMED_SCENES = {"MESH10M": MESH_SCENE % (3200, 1563), "MESH1M": MESH_SCENE % (1000, 501), "MESH100K": MESH_SCENE % (320, 157)}
 
 
+def note(msg):
+    """progress on stderr: a long stage (a 10 M-triangle upload, the CPU baseline) must not look like a hang"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +92,9 @@ def main():
     scene_name = args.scene
     args.scene = NAMED_SCENES.get(scene_name, scene_name)
     fs = rt.FrontScene(args.scene, "fastblue", optimize=True)
+    note("scene built")
     gs = rt.GpuScene(fs.desc)
+    note("scene uploaded")
     # contiguous row bands; every rank traces its own halo, so the data path has no exchange
     sh = rt.sharding
     if world > 1:
@@ -110,6 +121,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    note("warmup done")
     rt.rt_lib().rt_set_option(b"time_kernels", 1)      # HIP events around every k_visual launch of the timed region
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -126,6 +138,7 @@ def main():
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    note("timed steps done")
     rt.rt_lib().rt_set_option(b"time_kernels", 0)
     tot = torch.tensor([float(rays), float(samples), dt, t_trace], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -146,6 +159,7 @@ def main():
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])
+        note("roofline probe done")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene, scene_name)
         print(json.dumps(res))
@@ -211,11 +225,13 @@ def cpu_baseline(ge, rt, scene, name):
     For the mesh workloads the oracle tests every triangle per ray (the reference has no hierarchy over triangles
     either: ObjectFormat.cpp holds flat arrays), so the sample is a few hundred rays."""
     ob = ge.load_oracle()
-    raw = rt.FrontScene(scene, "fastblue", optimize=False)
+    sampler = "test" if name.startswith("MESH") else "fastblue"     # one ray per pixel: FastBlue would cast a whole tile of 1600
+    raw = rt.FrontScene(scene, sampler, optimize=False)
     osc = ob.OracleScene(raw.desc)
+    note("oracle scene built")
     w, h, spp = (512, 288, 16) if name == "S0" else (640, 360, 16)     # about 15-25 s of single-thread work
     if name.startswith("MESH"):
-        w, h, spp = {"MESH10M": (12, 8, 1), "MESH1M": (40, 24, 1)}.get(name, (80, 48, 1))
+        w, h, spp = {"MESH10M": (12, 8, 1), "MESH1M": (40, 24, 1)}.get(name, (128, 72, 1))
     scene = name
     rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
     st = rt.RtStats()
@@ -223,7 +239,7 @@ def cpu_baseline(ge, rt, scene, name):
     osc.render(w, h, spp, rd, st, threads=1)
     dt = time.perf_counter() - t0
     return {"value": st.rays() / dt, "unit": "rays/s", "cores": 1, "kind": "port",
-            "sample": "%s %dx%d %d spp FastBlue, %d rays in %.1f s, single thread (the reference is single-threaded)" % (scene, w, h, spp, st.rays(), dt)}
+            "sample": "%s %dx%d %d spp %s, %d rays in %.1f s, single thread (the reference is single-threaded)" % (scene, w, h, spp, "FastBlue" if sampler == "fastblue" else "one ray per pixel", st.rays(), dt)}
 
 
 if __name__ == "__main__":

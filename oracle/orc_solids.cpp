@@ -382,7 +382,10 @@ static void slab_hits(Node *s, const Ray &ray, Ctx &cx, HitList &out)        /* 
    misses), with the reference's test put right in two places (second barycentric bound u + v > 1; t = f * Dot(e2, q))
    and the parallel test made scale free; crossings with t >= 0 are kept, the RT_MAXROOTS_ORC nearest of them in
    (t, triangle index) order; an odd number of crossings ahead means the origin is inside, which HitList learns from
-   one root behind the origin; normals are Cross(e1, e2), transformed late like any other. */
+   one root behind the origin; normals are Cross(e1, e2), transformed late like any other.
+   PARITY UNPINNED by the reference: it holds no fixture, test or output for ray-traced meshes.  What
+   pins this routine is indirect: a cube of twelve triangles must give Cube's hit lists and a fine sphere mesh must
+   converge to Sphere (tests/test_cpu_oracle.py). */
 static void mesh_hits(Node *mn, const Ray &ray, Ctx &cx, HitList &out)
 {
     out.clear();

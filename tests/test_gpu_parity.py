@@ -547,3 +547,26 @@ def test_mesh_at_scale_converges_to_the_quadric(gpu):
     assert sa.hit_overflow == 0 and sa.samples == sb.samples
     assert abs(sa.rays() - sb.rays()) <= 2e-3 * sb.rays()
     assert _rel_rmse(a, b) < 2e-2 and np.abs(a - b).mean() < 1e-3 * b.mean() + 1e-4
+
+
+def test_mesh_keeps_the_nearest_sixteen_crossings(gpu, oracle):
+    """MAXHITS (Solids.h:20) for meshes, policy Q14: a ray that crosses one mesh more than sixteen times keeps the sixteen
+    nearest crossings, on the device as in the oracle (ten cubes in a row as ONE mesh: twenty crossings down the axis)."""
+    verts, tris = [], []
+    cube_v = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)]
+    cube_f = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (3, 6, 2), (3, 7, 6), (0, 4, 7), (0, 7, 3), (1, 2, 6), (1, 6, 5)]
+    for c in range(10):
+        base = len(verts)
+        verts += [(0.3 * x, 0.3 * y, 0.2 * z - 1.0 * c) for x, y, z in cube_v]
+        tris += [(a + base, b + base, cc + base) for a, b, cc in cube_f]
+    body = "(mesh %d %d %s %s)" % (len(verts), len(tris), " ".join("%r %r %r" % v for v in verts), " ".join("%d %d %d" % t for t in tris))
+    opt, raw, g, o = _pair(gpu, oracle, "(scene (model (material 0.9 auto g_sRed plastic none none %s)))" % body, "test")
+    rng = np.random.default_rng(29)
+    n = 2000
+    org = np.tile(np.array([0.0, 0.0, 3.0]), (n, 1)) + rng.normal(0, 0.08, (n, 3))
+    dr = np.concatenate([rng.normal(0, 0.01, (n, 2)), -np.ones((n, 1))], axis=1)
+    gr = g.intersect(org, dr, max_hits=20)
+    orr = o.intersect(org, dr, max_hits=20)
+    assert orr[0].max() == 16 and (orr[0] == 16).mean() > 0.5
+    for x, y in zip(gr, orr):
+        assert np.array_equal(x, y)
