@@ -159,6 +159,11 @@ def main():
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])
+        if scene_name.startswith("MESH"):
+            res["roofline"]["note"] = ("mesh workload: 88 % of the GPU time is the mesh walk inside the FULL k_shadow / k_visual launches "
+                                       "(profiles/r01_h_MESH10M_4k64_kernel_stats.csv), latency-bound on divergent 128-byte BVH node and 80-byte "
+                                       "triangle reads (about 15 nodes + 11 triangles = 2.8 KB per mesh ray, tools/mesh_count.py); the figures in "
+                                       "this object are the frame-record bytes of the timed k_visual launches only")
         note("roofline probe done")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene, scene_name)
