@@ -201,6 +201,8 @@ struct __attribute__((aligned(16))) HitRec {
 RT_DEV void hit_add_tex(HitRec &h, int tex) { if (tex >= 0 && h.ntex < RT_MAX_TEX) { h.texpack |= (uint32_t)tex << (8 * h.ntex); h.ntex++; } }
 
 
+/* which dynamic limit a ray ran into (Arena::overflow, reported in the error text) */
+enum { OVF_ARENA = 1, OVF_LISTS = 2, OVF_REGIONS = 4, OVF_CAND = 8, OVF_BVH_STACK = 16, OVF_MESH_STACK = 32 };
 struct Arena {              /* private (scratch) memory: lane-interleaved, uniform indices coalesce */
     HitRec   h[RT_ARENA];
     uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
@@ -275,7 +277,7 @@ __device__ void hit_list(W &w, Arena &A, int tag, uint16_t prim, int leaf_affine
     int nout = w.count - first;
     if (nout <= 0) return;
     if (A.top + nout > RT_ARENA) arena_compact(A);
-    if (A.top + nout > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
+    if (A.top + nout > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     int inside = w.inside_inf;
     for (int i = w.count - 1; i >= first; --i) {
@@ -333,7 +335,7 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
     else if (L >= 1 && t0 < w.eps) { t0 = 0.0; n0 = d3(0.0, 0.0, 0.0); }
     if (L <= 0) return;
     if (A.top + L > RT_ARENA) arena_compact(A);
-    if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow = 1; return; }
+    if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     const int last_in = w.inside_inf ? 1 : 0;
     HitRec h;
@@ -648,7 +650,7 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
         bool hit[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
-        if (sp + 4 > RT_MESH_STACK) { A.overflow = 1; break; }
+        if (sp + 4 > RT_MESH_STACK) { A.overflow |= OVF_MESH_STACK; break; }
         unsigned mask = 0;
         int c4[4];
 #pragma unroll
@@ -734,7 +736,7 @@ __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
     if (A.top + lc + rc > RT_ARENA) arena_compact(A);
     int ls = A.l_start[li], rs = A.t_start;
     int out = A.top, nout = 0;
-    if (out + lc + rc > RT_ARENA) { A.overflow = 1; A.nlist -= 1; A.top = rs; list_reload_top(A); list_retag_top(A, tag); return; }
+    if (out + lc + rc > RT_ARENA) { A.overflow |= OVF_ARENA; A.nlist -= 1; A.top = rs; list_reload_top(A); list_retag_top(A, tag); return; }
     int il = 0, ir = 0;
     uint16_t ml = 0, mr = 0;
     double prev = mats[0].density;
@@ -876,7 +878,7 @@ RT_DEV unsigned bvh4_test(const double *nb, const CullRay &c, int32_t child[4])
 __device__ int region_candidates(const RtDevScene &S, const SceneLds &L, const RtRegion &rg, const CullRay &cr, uint16_t *cand, int &overflow)
 {
     int n = 0;
-    for (int k = 0; k < rg.n_always; k++) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)S.region_always[rg.always0 + k]; else overflow = 1; }
+    for (int k = 0; k < rg.n_always; k++) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)S.region_always[rg.always0 + k]; else overflow |= OVF_CAND; }
     if (rg.bvh_root >= 0) {
         const int lane = threadIdx.x;
         int sp = 0;
@@ -888,9 +890,9 @@ __device__ int region_candidates(const RtDevScene &S, const SceneLds &L, const R
             else hit = bvh4_test((const double *)(S.bvh + node), cr, child);
             for (int k = 3; k >= 0; k--) {
                 if (!(hit & (1u << k))) continue;
-                if (child[k] < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~child[k]); else overflow = 1; }
+                if (child[k] < 0) { if (n < RT_MAX_CAND) cand[n++] = (uint16_t)(~child[k]); else overflow |= OVF_CAND; }
                 else if (sp < RT_BVH_STACK) RT_LDS_STACK(L, sp++, lane) = (uint16_t)child[k];
-                else overflow = 1;
+                else overflow |= OVF_BVH_STACK;
             }
             if (sp == 0) break;
             node = RT_LDS_STACK(L, --sp, lane);
@@ -1048,13 +1050,13 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             break;
         case OP_REGION: {
             const RtRegion rg = S.regions[in.a];
-            if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow = 1; pc = rg.end_pc; break; }
+            if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow |= OVF_REGIONS; pc = rg.end_pc; break; }
             uint16_t *cd = cands[nrf];
             int ov = 0;
             PROF_BEGIN(tb);
             const int nc = region_candidates(S, L, rg, cr, cd, ov);
             PROF_END(A, 1, tb);
-            if (ov) A.overflow = 1;
+            A.overflow |= ov;
             if (nc == 0) { pc = rg.end_pc; break; }
             if (nrf > 0) saved[nrf - 1] = cf;
             cf.ncand = nc; cf.pos = 0; cf.base_lists = A.nlist; cf.nl_before = A.nlist; cf.out_tag = in.tag;
@@ -1151,7 +1153,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 if (A.top + 1 <= RT_ARENA && A.nlist < RT_LIST_STACK) {
                     list_push(A, A.top, 0, 2 * in.b + 1);
                     merge_top(A, c.intersect ? MERGE_MIN : MERGE_DIFF, S.mats, in.tag);
-                } else A.overflow = 1;
+                } else A.overflow |= OVF_ARENA;
             }
             break;
         }

@@ -21,7 +21,7 @@
 #define RT_MAX_AFFINE_DEPTH 12      /* nested (merged) affine levels on a root-to-leaf path */
 #define RT_MAX_TEX          4       /* textured Material/Surface ancestors per hit */
 #define RT_LIST_STACK       24      /* pending non-empty hit lists per ray */
-#define RT_ARENA            64      /* working hits per ray (private memory) */
+#define RT_ARENA            256     /* working hits per ray (private memory) */
 #define RT_MAX_LIGHTS       8
 #define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
 #define RT_MAX_CAND         64      /* children of one union region whose boxes a ray may touch */

@@ -461,7 +461,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         Arena A;
         int start;
         int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start);
-        if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+        if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
         for (int q = 1; q < 8; q++) prof_v[q] = A.prof[q];
@@ -656,7 +656,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         Arena A;
         int start;
         int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, 1.0, A, start);
-        if (A.overflow) atomicAdd(&P.counters[CTR_OVERFLOW], 1);
+        if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
         int i = 0, pm = 0;
         if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
@@ -881,7 +881,7 @@ __global__ void __launch_bounds__(256) k_probe_intersect(const RtDevScene Sv, in
     Arena A;
     int start;
     int count = intersect_scene<false>(S, lds, ray, RT_INFINITY, A, start);
-    if (A.overflow) atomicAdd(overflow, 1);
+    if (A.overflow) atomicOr(overflow, A.overflow);
     out_count[k] = count;
     for (int i = 0; i < max_hits; i++) {
         size_t o = (size_t)k * max_hits + i;

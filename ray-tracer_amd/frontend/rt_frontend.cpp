@@ -411,6 +411,26 @@ Solid *IcosahedronCage(double r, double rs) { return cage(rgvIcosahedron, 12, 1.
 Solid *DodecahedronCage(double r, double rs) { return cage(rgvDodecahedron, 20, 0.8, r, rs, false); }
 Solid *HexahedronCage(double r, double rs) { return cage(rgvCube, 8, 1.2, r, rs, false); }
 Solid *OctahedronCage(double r, double rs) { return cage(rgvOctahedron, 6, 1.9, r, rs, false); }
+/* Solids.cpp:1880-1917: turns of a helix out of half tori, tilted alternately by asin(zRepeat / 4) */
+Solid *PseudoHelix(double r, double zRepeat, double fAng)
+{
+    const double tilt = asin(zRepeat / 4.0), c = sqrt(1.0 - zRepeat * zRepeat / 16.0), e = 0.00001;
+    Solid *ps = 0;
+    for (int n = 0; fAng >= 0.0 * D_PI; fAng -= 2.0 * D_PI, n++) {
+        Solid *a, *b = 0;
+        if (fAng < D_PI) a = new AngularClip(0.0 - e, fAng + e, new Torus(r));
+        else {
+            a = new AngularClip(0.0 - e, D_PI + e, new Torus(r));
+            b = new AngularClip(D_PI - e, (fAng < 2.0 * D_PI ? fAng : 2.0 * D_PI) + e, new Torus(r));
+            b = new Translate(0.0, -c, 0.0, new Rotate(-tilt, 0.0, 0.0, new Translate(0.0, 1.0, 0.0, b)));
+        }
+        a = new Translate(0.0, -c, 0.0, new Rotate(+tilt, 0.0, 0.0, new Translate(0.0, 1.0, 0.0, a)));
+        if (b) a = new Union(a, b);
+        a = new BoundingBox(a);
+        ps = n == 0 ? a : (Solid *)new Union(ps, new Translate(0.0, 0.0, -zRepeat * n, a));
+    }
+    return new BoundingBox(new Translate(0.0, 0.0, -zRepeat / 2.0, new Scale(1.0, 1.0 / c, 1.0, ps)));
+}
 Solid *Diskoid(double r) { return new BoundingBox(new Union(new Torus(r), new Scale(1.0, 1.0, r, new Cylinder))); }
 Solid *Rodoid(double r)
 {

@@ -465,6 +465,7 @@ Solid *IcosahedronCage(double r, double rs);
 Solid *DodecahedronCage(double r, double rs);
 Solid *Diskoid(double r);
 Solid *Rodoid(double r);
+Solid *PseudoHelix(double r, double zRepeat, double fAng = 2.0 * D_PI);   /* Solids.cpp:1880-1917 */
 Solid *Squareoid(double r);
 Solid *Knoboid(double r, double z = 1.0);
 Solid *Knoboid2(double r, double z = 1.0);

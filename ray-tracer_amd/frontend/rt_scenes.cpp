@@ -12,6 +12,11 @@
  *   S2  DistributedRayTracer's scene (DistributedRayTracing.cpp:56-150): IcosahedronCage in polished
  *       blue plastic over a floor inside a NOSHADE sky dome, ApertureCamera(1.4, 24, (0,0,9), 35)
  *       (the commented camera line :128), area + point light, QIndex1(0).
+ *   S4  one frame of Laboratory() (LaboratoryAnimation.cpp:387-442): five bumpy spectral-metal balls, a stopcock, a
+ *       five-neck Florence flask on a copper stand, an Erlenmeyer flask, a condenser envelope of length t with a
+ *       spiral tube inside, all Pyrex; floor and sky dome of Environment (:368-385); HavercosineLight ambient, one
+ *       point light, StereographicCamera((0,0,12)).  "S4" is the frame t = 4.5; "S4@t" any t of the animation
+ *       (3 <= t <= 6 there).
  * Argument evaluation order where the reference leaves it to the compiler (RandomDouble() calls
  * as constructor arguments): right to left, which is what both MSVC and g++ do.
  */
@@ -166,6 +171,183 @@ static int build_S2(RayTracer &rt)      /* DistributedRayTracer, DistributedRayT
     Spectrum blue = (g_sEqualWhite + g_sBlue) * 0.5;
     ps = new Surface(SURF_POLISHED, 0, new Material(0.7, REFRACT_PYREX, blue, MAT_PLASTIC, 0, ps));
     rt.psModel = lab_environment(ps, rt);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ S4 ----
+ * The glassware grammar of LaboratoryAnimation.cpp: every vessel is (outer shape) minus (inner shape), wall THICK. */
+namespace lab {
+const double THICK = 0.05, TUBE = 0.25, f90 = 90.0 * D_PI / 180.0;
+
+Solid *shell(Solid *outer, Solid *inner) { return new Difference(outer, inner); }
+Solid *rim(double z) { return new Translate(0.0, 0.0, z, new Scale(TUBE + THICK, TUBE + THICK, 2.0 * THICK, new Sphere)); }
+
+Solid *connect_part(double r, double rr, double w, double theta, double grow, double eps)   /* one wall of Connect, :14-66 */
+{
+    const double R1 = TUBE, R2 = 3.0 / 4.0 * TUBE;
+    Solid *hyp = MakeIntersection(new Scale(1.0, 1.0, 1.0, new ConeHyperCylinder(r / rr)),
+                                  new Scale(1.0, 1.0, 0.5 + grow, new Translate(0.0, 0.0, 1.0 - (grow != 0.0 ? 0.00001 : 0.0), new Cube)));
+    hyp = new Translate(0.0, 0.0, w - 3.0 * TUBE - (grow != 0.0 ? 0.0 : 0.00001), new Scale(rr, rr, 2.0 * TUBE + grow, hyp));
+    Solid *t1 = new Scale(R1, R1, R1, new AngularClip(D_PI - eps, 1.5 * D_PI + eps, new Torus(r / R1)));
+    t1 = new Translate(w - 2.0 * TUBE, 0.0, w - 3.0 * TUBE, new Rotate(f90, 0.0, 0.0, t1));
+    const double eps2 = grow != 0.0 ? 0.0001 : 0.0;
+    Solid *t2 = new Scale(R2, R2, R2, new AngularClip(theta - eps2, 1.0 * D_PI + eps2, new Torus(r / R2)));
+    t2 = new Translate(TUBE, R2, w - 3.0 * TUBE - TUBE, t2);
+    return MakeUnion(hyp, t1, t2);
+}
+Solid *Connect(double fAng)                         /* :14-66 */
+{
+    const double w = 3.0 * TUBE, r = 0.5 * TUBE;
+    const double theta = 0.5 * D_PI - atan(3.0 / 4.0 / 1.0);
+    Solid *outer = connect_part(r, TUBE, w, theta, 0.0, 0.00001);
+    Solid *inner = connect_part(r - THICK, TUBE - THICK, w, theta, 0.0001, 0.001);
+    Solid *ps = shell(outer, inner);
+    ps = new Translate(0.0, 0.0, 2.0 * TUBE - w - TUBE, ps);
+    return new BoundingBox(new Rotate(0.0, 0.0, fAng + theta, ps));
+}
+Solid *bead(double r, double r1)
+{
+    return new Difference(new Scale(r1, r1, r1, new Sphere), new Rotate(0.5 * D_PI, 0.0, 0.0, new Scale(r - THICK, r - THICK, r1 + 0.001, new Cylinder)));
+}
+Solid *SpiralTube(double L)                         /* :96-137 */
+{
+    const double w = 3.0 * TUBE, cap1 = -w - 1.5 * TUBE, lMain = L + 2.0 * cap1, cap2 = -L - cap1;
+    const double r = 0.5 * TUBE, R = w - 2.0 * r, z = 2.0 * TUBE, fAng = 2.0 * D_PI * lMain / z;
+    double fRad = fAng + 0.5 * D_PI;
+    while (fRad > 2.0 * D_PI) fRad -= 2.0 * D_PI;
+    const double r1 = r * 1.05;
+    Solid *ps = new Scale(R, R, R, PseudoHelix(r / R, z / R, fAng));
+    ps = new Union(ps, new Rotate(0.0, 0.0, 0.5 * D_PI, new Translate(R, 0.0, 0.0, bead(r, r1))));
+    ps = new Union(ps, new Rotate(0.0, 0.0, -fRad + 1.0 * D_PI, new Translate(R, 0.0, -lMain, bead(r, r1))));
+    Solid *ps2 = new Scale(R, R, R, PseudoHelix((r - THICK) / R, z / R, fAng));
+    ps = new Translate(0.0, 0.0, cap1, new Difference(ps, ps2));
+    ps = new Union(ps, new Rotate(0.0, 0.0, 1.0 * D_PI, new Translate(0.0, 0.0, cap1 + w, new Scale(1.0, -1.0, +1.0, Connect(0.0)))));
+    ps = new Union(ps, new Rotate(0.0, 0.0, -fRad + 0.5 * D_PI, new Translate(0.0, 0.0, cap2 - w, new Scale(1.0, +1.0, -1.0, Connect(0.0)))));
+    ps = new Rotate(0.0, 0.5 * D_PI, 0.0, new Rotate(-f90, 0.0, 0.0, ps));
+    return new BoundingBox(ps);
+}
+Solid *CondensorEnvelope(double L)                  /* :139-179 */
+{
+    const double w = 3.0 * TUBE, end1 = 0.0, cap1 = -w - 1.5 * TUBE, zMain = cap1, lMain = L + 2.0 * cap1, cap2 = -L - cap1, end2 = -L - end1;
+    const double h = 0.5 * TUBE;
+    Solid *ps = MakeUnion(
+        rim(end1),
+        new Translate(0.0, 0.0, end1, new Scale(TUBE, TUBE, 2.0 * TUBE, new Translate(0.0, 0.0, -1.0, new Cylinder))),
+        new Translate(0.0, 0.0, cap1, new Scale(w, w, w, new Sphere)),
+        new Translate(w + h, 0.0, cap1, new Rotate(0.0, f90, 0.0, new Scale(h, h, TUBE, new Cylinder))),
+        new Translate(0.0, 0.0, zMain, new Scale(w, w, 0.5 * lMain, new Translate(0.0, 0.0, -1.0, new Cylinder))),
+        new Translate(w + h, 0.0, cap2, new Rotate(0.0, f90, 0.0, new Scale(h, h, TUBE, new Cylinder))),
+        new Translate(0.0, 0.0, cap2, new Scale(w, w, w, new Sphere)),
+        new Translate(0.0, 0.0, end2, new Scale(TUBE, TUBE, 2.0 * TUBE, new Translate(0.0, 0.0, +1.0, new Cylinder))),
+        rim(-L));
+    const double ti = TUBE - THICK, wi = w - THICK, hi = h - THICK;
+    Solid *ps2 = MakeUnion(
+        new Translate(0.0, 0.0, end1, new Scale(ti, ti, 2.5 * TUBE, new Translate(0.0, 0.0, -0.75, new Cylinder))),
+        new Translate(0.0, 0.0, cap1, new Scale(wi, wi, wi, new Sphere)),
+        new Translate(w + h, 0.0, cap1, new Rotate(0.0, f90, 0.0, new Scale(hi, hi, 1.01 * TUBE, new Cylinder))),
+        new Translate(0.0, 0.0, zMain, new Scale(wi, wi, 0.5 * lMain, new Translate(0.0, 0.0, -1.0, new Cylinder))),
+        new Translate(w + h, 0.0, cap2, new Rotate(0.0, f90, 0.0, new Scale(hi, hi, 1.01 * TUBE, new Cylinder))),
+        new Translate(0.0, 0.0, cap2, new Scale(wi, wi, wi, new Sphere)),
+        new Translate(0.0, 0.0, end2, new Scale(ti, ti, 2.5 * TUBE, new Translate(0.0, 0.0, +0.75, new Cylinder))));
+    return new BoundingBox(new Rotate(-f90, 0.0, 0.0, shell(ps, ps2)));
+}
+Solid *capped_barrel(double half)                   /* a tube section with a plain and a flanged end, StopCock :189-196 */
+{
+    return new Union(new Scale(TUBE, TUBE, half, new Cylinder),
+                     new Union(new Translate(0.0, 0.0, +half, new Scale(TUBE, TUBE, 2.0 * THICK, new Sphere)), rim(-half)));
+}
+Solid *StopCock(double deg)                         /* :181-206 */
+{
+    const double fAng = deg * D_PI / 180.0, ti = TUBE - THICK, tp = TUBE - THICK - 0.01;
+    Solid *sh = new Union(capped_barrel(2.0 * TUBE), new Rotate(-f90, 0.0, 0.0, capped_barrel(1.5 * TUBE)));
+    sh = new Difference(sh, new Scale(ti, ti, 2.5 * (TUBE + THICK), new Cylinder));
+    sh = new Difference(sh, new Rotate(-f90, 0.0, 0.0, new Scale(ti, ti, 2.0 * (TUBE + THICK), new Cylinder)));
+    Solid *plug = new Union(new Union(new Scale(tp, tp, 2.0 * TUBE, new Cylinder),
+                                      new Translate(0.0, 0.0, -2.0 * TUBE, new Scale(tp, tp, ti, new Sphere))),
+                            new Translate(0.0, 0.0, -2.5 * (TUBE + THICK), new Scale(0.3 * TUBE, 1.5 * TUBE, 0.5 * TUBE, new Sphere)));
+    plug = new Difference(plug, new Rotate(-f90 * 0.8, 0.0, 0.0, new Scale(0.25 * TUBE, 0.25 * TUBE, TUBE + THICK, new Cylinder)));
+    return new BoundingBox(new Rotate(0.0, f90, 0.0, new Union(sh, new Rotate(0.0, 0.0, fAng, plug))));
+}
+Solid *ErlenmeyerFlask(double r, double fNeck)      /* :232-256 */
+{
+    const double rt = 0.15, z = 2.0, k = 1.01 + rt;
+    Solid *body = new Scale(r, r, r, new Intersection(new Scale(k, k, k, new Translate(0.0, 0.0, 1.0, new Cube)), Hyperboloidoid(TUBE / r, rt, z)));
+    Solid *neck = new Union(new Translate(0.0, 0.0, 0.0, new Scale(TUBE, TUBE, fNeck, new Cylinder)), rim(0.0 - fNeck));
+    Solid *ps = new Rotate(-f90, 0.0, 0.0, new Union(neck, body));
+    const double ri = r - 2.0 * THICK;
+    body = new Scale(ri, ri, r - THICK, new Intersection(new Scale(k, k, k, new Translate(0.0, 0.0, 1.0, new Cube)),
+                                                          Hyperboloidoid((TUBE - THICK) / ri, rt, z)));
+    neck = new Translate(0.0, 0.0, 0.0, new Scale(TUBE - THICK, TUBE - THICK, fNeck + 2.1 * THICK, new Cylinder));
+    return new BoundingBox(shell(ps, new Rotate(-f90, 0.0, 0.0, new Union(neck, body))));
+}
+Solid *flask_neck(double r, double fNeck)
+{
+    return new Union(new Rotate(f90, 0.0, 0.0, new Translate(0.0, 0.0, r, new Scale(TUBE, TUBE, fNeck, new Cylinder))),
+                     new Rotate(f90, 0.0, 0.0, rim(r + fNeck)));
+}
+Solid *flask_bore(double r, double fNeck)
+{
+    return new Rotate(f90, 0.0, 0.0, new Translate(0.0, 0.0, r, new Scale(TUBE - THICK, TUBE - THICK, fNeck + 2.1 * THICK, new Cylinder)));
+}
+Solid *FlorenceFlask(double r, double fNeck, int nNecks)    /* :258-288 */
+{
+    const double f20 = 20.0 * D_PI / 180.0, fRad = nNecks > 1 ? 2.0 * D_PI / double(nNecks - 1) : 0.0;
+    Solid *ps = new Union(new Scale(r, r, r, new Sphere), flask_neck(r, fNeck));
+    for (int i = 0; i < nNecks - 1; i++) ps = new Union(ps, new Rotate(2.0 * f20, fRad * i + 0.5 * D_PI, 0.0, flask_neck(r, fNeck)));
+    Solid *ps2 = new Union(new Scale(r - THICK, r - THICK, r - THICK, new Sphere), flask_bore(r, fNeck));
+    for (int i = 0; i < nNecks - 1; i++) ps2 = new Union(ps2, new Rotate(2.0 * f20, fRad * i + 0.5 * D_PI, 0.0, flask_bore(r, fNeck)));
+    return new BoundingBox(new Translate(0.0, r, 0.0, shell(ps, ps2)));
+}
+Solid *Stand()                                      /* :312-328 */
+{
+    const double f = 1.05 / sqrt(2.0);
+    Solid *ps = new Torus(0.05 / f);
+    ps = new Union(ps, new Translate(1.0, 0.0, -0.5, new Scale(0.05, 0.05, 0.5, new Cylinder)));
+    ps = new Union(ps, new Translate(-0.5, +0.866, -0.5, new Scale(0.05, 0.05, 0.5, new Cylinder)));
+    ps = new Union(ps, new Translate(-0.5, -0.866, -0.5, new Scale(0.05, 0.05, 0.5, new Cylinder)));
+    ps = new Translate(0.0, f, 0.0, new Rotate(0.5 * D_PI, 0.0, 0.0, new Scale(f, f, f, ps)));
+    return new BoundingBox(new Material(0.9, g_sCopper, MAT_COPPER, new Surface(SURF_POLISHED, 0, ps)));
+}
+Solid *Glass(Solid *ps)                             /* :345-350 */
+{
+    return new Material(0.33, REFRACT_PYREX, g_sWater, MAT_TRANSPARENT, ColoredGlass, new Surface(SURF_POLISHED, 0, ps));
+}
+Solid *metal_ball(double x, double y, double z, const Spectrum &c, int luster)
+{
+    return new Translate(x, y, z, new Material(0.9, c, luster, new Surface(SURF_POLISHED, Bumpy, new Sphere)));
+}
+Solid *Environment(Solid *ps)                       /* :368-385 */
+{
+    Spectrum sBlue = (g_sBlue + g_sEqualWhite) * 0.5;
+    const double f20 = 20.0 * D_PI / 180.0;
+    ps = new Union(ps, new Translate(0.0, 5.0, -10.0, new Scale(12.0, 1.0, 12.0, new Material(0.9, g_sEqualWhite, MAT_PLASTIC, new Cube))));
+    ps = new Union(ps, new Scale(100.0, 100.0, 100.0, new Material(0.9, sBlue, MAT_PLASTIC, new HollowSphere)));
+    return new Rotate(-f20, 0.0, 0.0, ps);
+}
+}   // namespace lab
+
+static int build_S4(RayTracer &rt, double t)        /* Laboratory(), LaboratoryAnimation.cpp:387-442, the frame at time t */
+{
+    using namespace lab;
+    reset_globals();
+    Spectrum sBlue = (g_sBlue + g_sEqualWhite) * 0.5, s6500 = BlackBody(6500.0);
+    rt.plAmbient = new HavercosineLight(sBlue * 0.02, s6500 * 0.02);
+    rt.plPointLights = new PointLight(Point3(9.0, -6.5, 12.0), s6500 * 10000.0);
+    rt.psSample = new FastBlueSamplingTile;
+    rt.pcCamera = new StereographicCamera(Point3(0.0, 0.0, 12.0));
+    Solid *ps = MakeUnion(
+        metal_ball(-6.5, 2.5, -8.0, sBlue, MAT_GOLD),
+        metal_ball(-3.1, 2.5, -9.3, sBlue, MAT_IRON),
+        metal_ball(-0.9, 2.5, -10.7, sBlue, MAT_ALUMINUM),
+        metal_ball(+3.3, 2.5, -9.0, sBlue, MAT_OSMIUM),
+        metal_ball(+6.4, 2.5, -10.9, sBlue, MAT_COPPER),
+        Glass(new Translate(+2.5, 3.5, -0.9, new Rotate(0.5 * D_PI, 0.05 * D_PI, 0.0, StopCock(-20.0)))),
+        Glass(new Translate(-4.5, 2.8 - 1.3, -2.0, FlorenceFlask(1.2, 0.8, 5))),
+        new Translate(-4.5, 2.8, -2.0, Stand()),
+        Glass(new Translate(+4.0, 0.5, -4.5, ErlenmeyerFlask(1.5, 0.5))),
+        Glass(new Translate(+0.0, 0.5 * t, -0.5, new Rotate(0.0, -30.0 * D_PI / 180.0, 0.0, CondensorEnvelope(t)))),
+        Glass(new Translate(+0.0, 0.5 * t, -0.5, SpiralTube(t))));
+    rt.psModel = Environment(ps);
     return 0;
 }
 
@@ -431,6 +613,8 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     if (name == "S0") rc = build_S0(s->rt);
     else if (name == "S1") rc = build_S1(s->rt);
     else if (name == "S2") rc = build_S2(s->rt);
+    else if (name == "S4") rc = build_S4(s->rt, 4.5);
+    else if (name.compare(0, 3, "S4@") == 0) rc = build_S4(s->rt, atof(name.c_str() + 3));
     else {
         reset_globals();
         Parser ps(spec, &s->rt);

@@ -374,3 +374,23 @@ def test_mesh_solid_restatement_against_the_same_solid_made_of_planes(rt, oracle
     both = (a[0] == 2) & (b[0] == 2)
     assert both.sum() > 100 and (a[0] != b[0]).mean() < 0.02          # silhouette rays only
     assert np.abs(a[1][both] - b[1][both]).max() < 5e-3
+
+
+def test_laboratory_scene_script(rt, oracle):
+    """S4 = one frame of Laboratory() (LaboratoryAnimation.cpp:387-442).  Structure of what the front end builds: eleven
+    objects + floor + sky dome, six ColoredGlass Pyrex materials, five spectral metals with Bumpy surfaces and a copper
+    stand; the condenser grows with t (more helix turns = more nodes); Optimize() merges the affine chains; the oracle
+    renders it (finite, lit, several rays per sample through the glass)."""
+    fa = rt.FrontScene("S4@3.0", "fastblue", optimize=False)        # keep them alive: the descriptions point into them
+    fb = rt.FrontScene("S4@6.0", "fastblue", optimize=False)
+    assert fb.desc.contents.n_nodes > fa.desc.contents.n_nodes > 400
+    fs = rt.FrontScene("S4", "fastblue", optimize=False)
+    d = fs.desc.contents
+    mats = [d.nodes[i] for i in range(d.n_nodes) if d.nodes[i].type == 12]
+    assert sum(1 for m in mats if m.i2 == 1) == 5 and sum(1 for m in mats if 4 <= m.i0 <= 10) == 6      # ColoredGlass; spectral metals
+    assert d.n_lights == 1 and d.has_ambient and d.camera.type == 1 and d.camera.org[2] == 12.0
+    fo = rt.FrontScene("S4", "fastblue", optimize=True)
+    assert fo.desc.contents.n_nodes < d.n_nodes
+    st = rt.RtStats()
+    img, _, n = oracle.OracleScene(fs.desc).render(64, 36, 1, rt.RtRenderDesc(64, 36, 1.0, 0, 0), st, threads=4)
+    assert np.isfinite(img).all() and img.mean() > 0.05 and st.rays() > 5 * n

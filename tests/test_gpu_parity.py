@@ -570,3 +570,19 @@ def test_mesh_keeps_the_nearest_sixteen_crossings(gpu, oracle):
     assert orr[0].max() == 16 and (orr[0] == 16).mean() > 0.5
     for x, y in zip(gr, orr):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["S4@3.0", "S4", "S4@6.0"])
+def test_laboratory_frames_match_oracle(gpu, oracle, name):
+    """8(f) conformance case: frames of Laboratory() (LaboratoryAnimation.cpp:387-442; BASELINE configs[4] without the
+    Atmosphere stub) -- Pyrex glassware built from differences of unions of quadrics, tori, angular clips and
+    hyperboloids under nested bounding boxes, a pseudo-helix of up to eight turns, ColoredGlass, five bumpy spectral
+    metals, a copper stand.  Deep hit lists (the reason RT_ARENA is 256).  Ray counts equal, image to the tolerance of
+    the libm calls on the path (torus cubic, exp)."""
+    opt, raw, g, o = _pair(gpu, oracle, name, "fastblue")
+    img, st = g.render(160, 90, 4)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(160, 90, 4, gpu.RtRenderDesc(160, 90, 4.0, 0, 0), ost, threads=8)
+    assert st.samples == n and st.hit_overflow == 0
+    assert abs(st.rays() - ost.rays()) <= 1e-4 * ost.rays() and st.rays() > 8 * n
+    assert _rel_rmse(img, ref) <= 1e-5 and np.abs(img - ref).max() <= 1e-2
