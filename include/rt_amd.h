@@ -124,6 +124,8 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    "full_waves" (1 / 2, default 2: waves per SIMD the kernels for the rare features -- tori, meshes, textures,
    propagators, spectral metals -- are built for; two hide the latency of mesh walks, one has no register spills; at
    rt_scene_upload),
+   "full_tables" (0/1, default 1: those kernels also read chain records and scene tables from LDS when two of their
+   workgroups fit a CU; at rt_scene_upload),
    "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */
 int  rt_set_option(const char *name, int64_t value);
 

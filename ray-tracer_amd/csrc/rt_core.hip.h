@@ -1071,7 +1071,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             /* CH_LDS: every chain record of the scene is staged in LDS (decided per launch, so that the loads below
                are LDS loads and not generic ones) */
             const RtChain &ch = CH_LDS ? L.chains[in.a] : S.chains[in.a];
-            if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b) goto region_ret; break; }
+            if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b & 1) goto region_ret; break; }
             DRay r = cur;
             if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
                 DRay nr;
@@ -1102,7 +1102,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 }
                 PROF_END(A, 2, tp);
             }
-            if (in.b) goto region_ret;
+            if (in.b & 1) goto region_ret;
             break;
         }
         case OP_RET:

@@ -48,7 +48,7 @@ enum RtOp {
     OP_RETAG,       /* pass the pending list (if any) on to a new consumer: Union/Difference with a null child */
     OP_REGION,      /* a: union region index, tag: consumer of the region's result */
     OP_RET,         /* a: union region index: end of one region child's code */
-    OP_CHAIN,       /* a: chain index: [box] affine* primitive (material|surface)* in one step; b != 0: followed by the region's OP_RET */
+    OP_CHAIN,       /* a: chain index: [box] affine* primitive (material|surface)* in one step; b bit 0: followed by the region's OP_RET, bit 1: the primitive is a torus or a mesh */
     OP_MESH         /* a: primitive index (RtPrim.plane0 = mesh index): closed triangle mesh, policy Q14 */
 };
 

@@ -510,7 +510,7 @@ struct Flattener {
             o.region_child_pc[rg.child_pc0 + k] = (int)o.prog.size();
             size_t before = o.prog.size();
             emit(kids[k], 2 * rg.uid, true);
-            if (o.prog.size() == before + 1 && o.prog.back().op == OP_CHAIN) o.prog.back().b = 1;    /* chain + return in one step */
+            if (o.prog.size() == before + 1 && o.prog.back().op == OP_CHAIN) o.prog.back().b |= 1;    /* chain + return in one step */
             else push(OP_RET, ri, 0, 0);
         }
         region_depth--;
@@ -612,7 +612,7 @@ struct Flattener {
         for (int k = 0; k < ch.n_affine; k++) { affine_stack.pop_back(); fwd_stack.pop_back(); }
         tex_depth -= tex_added;
         o.chains.push_back(ch);
-        push(OP_CHAIN, (int)o.chains.size() - 1, 0, tag);
+        push(OP_CHAIN, (int)o.chains.size() - 1, (op == OP_TORUS || op == OP_MESH) ? 2 : 0, tag);     /* b bit 1: a long primitive (see the interpreter's parking) */
         return true;
     }
 

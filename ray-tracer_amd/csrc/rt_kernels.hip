@@ -423,7 +423,9 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     const RtDevScene &S = SL;
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
-    const int n = LITE ? (f1 - f0) : P.counters[CTR_SLOW_V];
+    /* FULL: over the slow list the LITE launch left, or (f1 > f0: a small level, no LITE launch before it) over the frames themselves */
+    const bool direct = LITE || f1 > f0;
+    const int n = direct ? (f1 - f0) : P.counters[CTR_SLOW_V];
     int *const work = &P.counters[LITE ? CTR_WORK_V : CTR_WORK_VS];
     const int wlane = threadIdx.x & 63;
   int wnext = 0, wlimit = 0;      /* the wave's current claim: items [wnext, wlimit) */
@@ -439,7 +441,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     wnext += 64;
     const bool live = wbase + wlane < n;
     int f;
-    if constexpr (LITE) f = f0 + wbase + wlane;
+    if (direct) f = f0 + wbase + wlane;
     else f = live ? P.slow_v[wbase + wlane] : 0;
 #ifdef RT_PHASE_PROF
     long long prof_t0 = clock64();
@@ -624,7 +626,8 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     RtDevScene SL = Sv;
     const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
-    const int n = LITE ? nrays : P.counters[CTR_SLOW_S];
+    const bool direct = LITE || nrays > 0;      /* FULL: nrays == 0 = the slow list of the LITE launch before it */
+    const int n = direct ? nrays : P.counters[CTR_SLOW_S];
     int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
     const int wlane = threadIdx.x & 63;
   int wnext = 0, wlimit = 0;      /* the wave's current claim: items [wnext, wlimit) */
@@ -640,7 +643,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     wnext += 64;
     const bool live = wbase + wlane < n;
     int s;
-    if constexpr (LITE) s = wbase + wlane;
+    if (direct) s = wbase + wlane;
     else s = live ? P.slow_s[wbase + wlane] : 0;
     bool bail = false;
     if (live) {
