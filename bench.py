@@ -6,7 +6,7 @@ shading with shadow / secondary rays and reconstruction, with the scene already 
 image left in HBM (rt_render_device).  At N > 1 the image rows are split across ranks (no data-path
 collective; the finished row bands are gathered to rank 0 with RCCL, inside the timed region).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S0|S1|S2] [--width W --height H --spp S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S0|S1|S2|S4|S4@t|MESH100K|MESH1M|MESH10M|"(scene ...)"] [--width W --height H --spp S]
                   [--no-cpu-baseline]
 
 Default workload = BASELINE.json configs[1]: the as-checked-in TestScene.cpp scene ("S0": 257 spheres,
@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 W_AFFINE, W_QUADRIC, W_BOX, W_MERGE, W_SHADE, W_SHADE_LIGHT = 33.0, 57.0, 30.0, 6.0, 250.0, 60.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = half of the 157.3 TF FP32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
-# PMC measurement of the same workload (a copy of profiles/r01_f_pmc_traffic_k_visual.json kept where GPU runs can read it)
+# PMC measurement of the same workload (a copy of profiles/r01_h_pmc_traffic_k_visual.json kept where GPU runs can read it)
 TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic_k_visual.json")
 
 

@@ -589,10 +589,10 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
-    for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 16 cycles */
+    for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 1024 cycles (int counters: 16 overflowed on long frames) */
         int v = prof_v[q];
         for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
-        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 4);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 10);
     }
 #endif
     if (!live || bail) continue;

@@ -601,7 +601,7 @@ static char s_scene_err[512];
 
 extern "C" const char *rtf_last_error() { return s_scene_err[0] ? s_scene_err : rt_frontend_last_error(); }
 
-/* spec: "S0" | "S1" | "S2" | "(scene ...)".  sampler: "", "test", "jitter" or "fastblue" overrides the scene's tile.
+/* spec: "S0" | "S1" | "S2" | "S4" | "S4@t" | "(scene ...)".  sampler: "", "test", "jitter" or "fastblue" overrides the scene's tile.
    optimize != 0 calls psModel->Optimize() before flattening (what every reference driver does). */
 extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int optimize)
 {
