@@ -586,3 +586,51 @@ def test_laboratory_frames_match_oracle(gpu, oracle, name):
     assert st.samples == n and st.hit_overflow == 0
     assert abs(st.rays() - ost.rays()) <= 1e-4 * ost.rays() and st.rays() > 8 * n
     assert _rel_rmse(img, ref) <= 1e-5 and np.abs(img - ref).max() <= 1e-2
+
+
+SCENE_TINY = """(scene (model %s)
+ (ambient (scale (blackbody 6500) 0.05)) %s
+ (camera perspective 0 0 6 40) (sampler fastblue))"""
+ONE_LIGHT = "(pointlight -10 -10 10 (scale (blackbody 6500) 2000))"
+BALL = "(material 0.9 auto g_sRed plastic none none (sphere))"
+
+
+@pytest.mark.parametrize("model,lights,w,h,spp", [
+    ("(null)", ONE_LIGHT, 16, 9, 4),                    # nothing to hit: every sample is background
+    (BALL, "", 16, 9, 4),                               # no point lights: ambient only, no shadow rays
+    (BALL, ONE_LIGHT, 1, 1, 4),                         # one pixel
+    (BALL, ONE_LIGHT, 7, 3, 1),                         # smaller than one sampling tile, 1 spp
+    (BALL, ONE_LIGHT, 41, 40, 2.25),                    # one pixel past a tile edge; supersampling factor 1.5
+    (BALL, ONE_LIGHT, 40, 80, 9),                       # exact tile multiples
+    (BALL, " ".join("(pointlight %d -10 10 (scale (blackbody 6500) 300))" % x for x in range(-8, 8, 2)), 24, 16, 4),    # 8 lights: RT_MAX_LIGHTS
+], ids=["null_model", "no_lights", "1x1", "7x3_1spp", "41x40_2.25spp", "40x80_9spp", "eight_lights"])
+def test_edge_cases_of_the_boundary_match_oracle(gpu, oracle, model, lights, w, h, spp):
+    """Edges of RayTracer::Render's contract (b): empty model, no lights, images smaller than a tile or one pixel past
+    it, fractional supersampling, the light limit.  No libm on these paths: images and ray counts must be equal."""
+    opt, raw, g, o = _pair(gpu, oracle, SCENE_TINY % (model, lights), "")
+    img, st = g.render(w, h, spp)
+    ost = gpu.RtStats()
+    ref, _, n = o.render(w, h, spp, gpu.RtRenderDesc(w, h, float(spp), 0, 0), ost, threads=2)
+    assert st.samples == n and (st.rays_primary, st.rays_shadow, st.rays_secondary) == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary)
+    assert np.array_equal(img, ref)
+    if model == "(null)":
+        assert st.rays_shadow == 0 and np.ptp(img.reshape(3, -1), axis=1).max() == 0.0
+    if not lights:
+        assert st.rays_shadow == 0 and img.max() > 0
+
+
+def test_bad_arguments_are_errors_not_crashes(gpu):
+    """(b) errors: the reference ignores them; the C ABI reports them."""
+    fs = gpu.FrontScene(SCENE_TINY % (BALL, ONE_LIGHT), "")
+    g = gpu.GpuScene(fs.desc)
+    for w, h, spp in ((0, 8, 4), (8, 0, 4), (8, 8, 0), (8, 8, -1)):
+        with pytest.raises(gpu.RtError):
+            g.render(w, h, spp)
+    with pytest.raises(gpu.RtError):
+        g.render(16, 16, 4, row0=9, row1=5)
+    nine = " ".join("(pointlight %d -10 10 (scale (blackbody 6500) 300))" % x for x in range(-9, 9, 2))
+    f9 = gpu.FrontScene(SCENE_TINY % (BALL, nine), "")
+    with pytest.raises(gpu.RtError):
+        gpu.GpuScene(f9.desc)
+    img, st = g.render(8, 8, 4)                      # the handle is still usable after the failures
+    assert st.samples > 0 and np.isfinite(img).all()
