@@ -111,7 +111,7 @@ void rt_random_skip(uint32_t state_xc[2], uint64_t ndraws);
    k_visual.  out9: 9 doubles. */
 int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out9);
 
-/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 2^24),
+/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 16,776,000 = 10485 sampling tiles),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
    "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
    "fuse_splat" (0/1, default 0: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled
@@ -124,6 +124,8 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    "full_waves" (1 / 2, default 2: waves per SIMD the kernels for the rare features -- tori, meshes, textures,
    propagators, spectral metals -- are built for; two hide the latency of mesh walks, one has no register spills; at
    rt_scene_upload),
+   "cell_order" (0/1, default 1: the samples of a FastBlue tile are traced cell by cell, which needs chunk_samples to be a
+   multiple of 1600; results do not depend on it),
    "full_tables" (0/1, default 1: those kernels also read chain records and scene tables from LDS when two of their
    workgroups fit a CU; at rt_scene_upload),
    "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */

@@ -318,15 +318,25 @@ RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const
     P.f_flags[f] = 0;
 }
 
+/* work item k of a chunk -> the sample it traces (RtSampleGrid::fb_order) */
+RT_DEV int trace_order(const RtSampleGrid &g, int64_t first, int k)
+{
+    if (!g.fb_order) return k;
+    const int64_t a = first + k;
+    const int i = (int)(a % RT_BLUE_N);
+    return k - i + (int)g.fb_order[i];
+}
+
 /* root frames for rays [0, n) of a chunk, frame index = ray index */
 __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir, const double *rays_aux)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const int k = trace_order(g, first, f);
     double aux[6];
     DRay r;
     root_ray(Sv, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
-    root_frame(Sv, P, k, k, r, aux);
+    root_frame(Sv, P, f, k, r, aux);
 }
 
 /* The same for scenes with a root cull (RtDevScene.root_cull): rays that miss every conservative box of the
@@ -350,6 +360,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         int k = k0 + it * 256 + threadIdx.x;
         bool keep = false;
         if (k < n) {
+            k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
             const bool masked = g.tile_mask && !rays_org && g.tile_mask[(first + k) / RT_BLUE_N] == 0;
             if (!masked) {
@@ -376,7 +387,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
     __syncthreads();
     for (int it = 0; it < RT_GEN_ITERS; it++) {
         if (!(keep_bits & (1u << it))) continue;
-        int k = k0 + it * 256 + threadIdx.x;
+        const int k = trace_order(g, first, k0 + it * 256 + threadIdx.x);
         double aux[6];
         DRay r;
         root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);

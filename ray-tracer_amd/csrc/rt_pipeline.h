@@ -75,6 +75,11 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     /* FASTBLUE: one byte per traced tile (tx * tiles_y_local + local ty), 0 = no ray through the tile can touch a box of
        the scene (k_tile_mask): k_generate_cull finishes its 1600 samples without generating them.  Null = not used. */
     const unsigned char *tile_mask;
+    /* FASTBLUE: the order in which the 1600 samples of a tile are TRACED: sorted by the 8x8-sample cell of the tile they
+       fall into (25 cells of about 64 samples), so that the 64 rays of a wave come from one or two neighbouring cells
+       instead of from all over the tile.  Which sample a work item is changes, nothing else does: results are stored
+       by sample index.  Null = trace in index order (chunks that do not start and end on tile boundaries). */
+    const unsigned short *fb_order;
     int     mask_skips_rgb;             /* the caller's reconstruction honours the mask: masked tiles' (black) sample colours are neither written nor read */
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
