@@ -117,7 +117,7 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    "fuse_splat" (0/1, default 0: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled
    image staying in LDS -- 10.6 GB less HBM at 4K / 64 spp, about 4 % slower -- or in two kernels through memory; same result),
    "persistent", "lds_chains" (0/1: launch geometry / chain records in LDS, for A/B runs),
-   "lds_tables" (0/1: stage the scene's small tables -- program, boxes, affines, materials, surfaces, region tables -- in LDS
+   "lds_tables" (0/1/2, default 1; 2 = the program and region tables alone when the rest does not fit: stage the scene's small tables -- program, boxes, affines, materials, surfaces, region tables -- in LDS
    next to the chain records when they fit; takes effect at rt_scene_upload),
    "tile_mask" (0/1: a pre-pass marks the sampling tiles no ray of which can touch a box of the scene; their samples end
    without being generated),

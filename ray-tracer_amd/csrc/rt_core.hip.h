@@ -338,6 +338,11 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
     if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     const int last_in = w.inside_inf ? 1 : 0;
+#ifdef RT_EXP_NONORMAL      /* experiment (wrong pictures): what would hit records without normals be worth? */
+#define HSTORE(dst, src) do { HitRec &d_ = (dst); d_.t = (src).t; d_.leaf_affine = (src).leaf_affine; d_.surf = (src).surf; d_.mat = (src).mat; d_.prim = (src).prim; d_.ntex = (src).ntex; d_.pad_ = 0; d_.texpack = (src).texpack; } while (0)
+#else
+#define HSTORE(dst, src) (dst) = (src)
+#endif
     HitRec h;
     h.leaf_affine = (uint32_t)(leaf_affine + 1); h.prim = prim; h.pad_ = 0;
     {
@@ -345,21 +350,21 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
         h.mat = (uint16_t)(((L - 1) & 1) ? !last_in : last_in);
         h.surf = (t0 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        A.h[A.top] = h;
+        HSTORE(A.h[A.top], h);
     }
     if (L >= 2) {
         h.t = t1; h.n = n1; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 2) & 1) ? !last_in : last_in);
         h.surf = (t1 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        A.h[A.top + 1] = h;
+        HSTORE(A.h[A.top + 1], h);
     }
     if (L >= 3) {
         h.t = t2; h.n = n2; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)last_in;
         h.surf = (t2 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        A.h[A.top + 2] = h;
+        HSTORE(A.h[A.top + 2], h);
     }
     list_push(A, A.top, L, tag);
     A.top += L;
@@ -796,11 +801,19 @@ struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int
 #define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * (L).stride + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
 /* 8-byte words of LDS the small scene tables take when staged (same arithmetic on the host: rt_scene_upload) */
-RT_HD int scene_table_words(const RtDevScene &S)
+/* Two groups, staged independently (RT_LDS_GROUP_* bits travel in the upper byte of the kernels' n_chains_lds argument):
+   CONTROL = what the interpreter's dependent lookups go through (program, regions, their child and LCA tables): small,
+   and every candidate of a union region costs two of them in a row; DATA = boxes, affines, materials, surfaces. */
+#define RT_LDS_GROUP_CONTROL 1
+#define RT_LDS_GROUP_DATA    2
+RT_HD int scene_table_words_control(const RtDevScene &S)
 {
-    return S.n_prog * (int)(sizeof(RtInstr) / 8) + S.n_boxes * (int)(sizeof(RtBox) / 8) + S.n_affines * (int)(sizeof(RtAffine) / 8) +
-           S.n_mats * (int)(sizeof(RtMaterialDev) / 8) + S.n_surfs * (int)(sizeof(RtSurfaceDev) / 8) + S.n_regions * (int)(sizeof(RtRegion) / 8) +
-           (S.n_child_pc + 1) / 2 + (S.n_lca + 1) / 2;
+    return S.n_prog * (int)(sizeof(RtInstr) / 8) + S.n_regions * (int)(sizeof(RtRegion) / 8) + (S.n_child_pc + 1) / 2 + (S.n_lca + 1) / 2;
+}
+RT_HD int scene_table_words_data(const RtDevScene &S)
+{
+    return S.n_boxes * (int)(sizeof(RtBox) / 8) + S.n_affines * (int)(sizeof(RtAffine) / 8) +
+           S.n_mats * (int)(sizeof(RtMaterialDev) / 8) + S.n_surfs * (int)(sizeof(RtSurfaceDev) / 8);
 }
 template <class T> RT_DEV const T *lds_stage(double *&cur, const T *src, int n)
 {
@@ -815,12 +828,13 @@ template <class T> RT_DEV const T *lds_stage(double *&cur, const T *src, int n)
 /* SL (optional): a copy of the scene description whose small tables -- program, boxes, affines, materials, surfaces,
    regions and their child / LCA tables -- point at LDS copies.  Their lookups are per-lane gathers (every lane is at
    its own instruction, material, box ...): in LDS they cost bank cycles, through the vector L1 one cache line each. */
-RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds, RtDevScene *SL = 0)
+RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_packed, RtDevScene *SL = 0)
 {
     extern __shared__ double rt_dyn_lds[];
     SceneLds L;
+    const int groups = n_chains_packed >> 24;
     L.n_nodes = S.n_bvh_lds;
-    L.n_chains = n_chains_lds;
+    L.n_chains = n_chains_packed & 0xFFFFFF;
     L.stride = blockDim.x;
     const int words_bvh = L.n_nodes * (int)(sizeof(RtBvhNode) / 8), words_ch = L.n_chains * (int)(sizeof(RtChain) / 8);
     const double *src = (const double *)S.bvh, *src2 = (const double *)S.chains;
@@ -829,15 +843,17 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_lds, RtDevScene
     L.bvh = rt_dyn_lds;
     L.chains = (const RtChain *)(rt_dyn_lds + words_bvh);
     double *cur = rt_dyn_lds + words_bvh + words_ch;
-    if (SL) {
+    if (SL && (groups & RT_LDS_GROUP_CONTROL)) {
         SL->prog = lds_stage(cur, S.prog, S.n_prog);
+        SL->regions = lds_stage(cur, S.regions, S.n_regions);
+        SL->region_child_pc = lds_stage(cur, S.region_child_pc, S.n_child_pc);
+        SL->region_lca = lds_stage(cur, S.region_lca, S.n_lca);
+    }
+    if (SL && (groups & RT_LDS_GROUP_DATA)) {
         SL->boxes = lds_stage(cur, S.boxes, S.n_boxes);
         SL->affines = lds_stage(cur, S.affines, S.n_affines);
         SL->mats = lds_stage(cur, S.mats, S.n_mats);
         SL->surfs = lds_stage(cur, S.surfs, S.n_surfs);
-        SL->regions = lds_stage(cur, S.regions, S.n_regions);
-        SL->region_child_pc = lds_stage(cur, S.region_child_pc, S.n_child_pc);
-        SL->region_lca = lds_stage(cur, S.region_lca, S.n_lca);
     }
     L.stack = (uint16_t *)cur;
     L.mstack = (int *)(L.stack + RT_BVH_STACK * blockDim.x);    /* present only when the launch was sized for it: scenes with meshes, FULL kernels */
