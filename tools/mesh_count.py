@@ -1,3 +1,6 @@
+"""Node visits and triangle tests per mesh ray.  Needs the instrumented library:
+    RT_EXTRA_DEFS=-DRT_MESH_COUNT python3 -c 'import __graft_entry__ as g; g.build(force=True)'
+(rebuild without it afterwards)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, numpy as np
@@ -5,6 +8,8 @@ import __graft_entry__ as ge, bench
 rt = ge.load_package()
 torch.cuda.set_device(0)
 L = rt.rt_lib()
+if not hasattr(L, 'rt_debug_mesh_counts'):
+    raise SystemExit(__doc__)
 W,H,spp = 960,540,4.0
 planes = torch.zeros((3,H,W), dtype=torch.float32, device="cuda")
 for name, body in (("ico","(meshicosahedron)"),("1.6K","(meshblob 40 21 0.08 5)"),("100K","(meshblob 320 157 0.08 5)"),("1M","(meshblob 1000 501 0.08 5)"),("sph100K","(meshsphere 320 157)")):
