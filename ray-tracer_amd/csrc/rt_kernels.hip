@@ -322,8 +322,8 @@ RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const
 RT_DEV int trace_order(const RtSampleGrid &g, int64_t first, int k)
 {
     if (!g.fb_order) return k;
-    const int64_t a = first + k;
-    const int i = (int)(a % RT_BLUE_N);
+    (void)first;                            /* chunks start on tile boundaries when fb_order is set (grid_device_tables, run_range) */
+    const int i = k % RT_BLUE_N;            /* 32-bit, by a constant: a 64-bit remainder here cost the generator 9 % */
     return k - i + (int)g.fb_order[i];
 }
 
@@ -1274,8 +1274,8 @@ __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int pla
         for (int k = 0; k < cnt; k++) {
             double y = (double)s_src[RT_RS_IDX(j0 + k)], fw = s_taps[k];
             sum += fw * y;
-            wsum += fw;
         }
+        wsum = T.wsum_uniform;          /* every destination adds the same taps in the same order: summed once on the host */
     } else if (staged) {
         const int j0 = i0 - base;
         for (int k = 0; k < cnt; k++) {
@@ -1335,8 +1335,9 @@ __global__ void __launch_bounds__(256) k_splat_resample_rows(const RtDevScene Sv
         const int q = RT_RS_IDX(j0 + k);
         sum0 += fw * (double)a0[q];
         sum1 += fw * (double)a1[q];
-        wsum += fw;
+        if (!T.uniform) wsum += fw;
     }
+    if (T.uniform) wsum = T.wsum_uniform;
     if (wsum != 0.0) { sum0 /= wsum; sum1 /= wsum; }
     const size_t rows = (size_t)(y1 - y0), o = (size_t)row * n_dst + id;
     if (half == 0) { dst3[o] = (float)sum0; dst3[rows * n_dst + o] = (float)sum1; }
@@ -1359,8 +1360,9 @@ __global__ void __launch_bounds__(256) k_resample_cols(const float *src, int pla
         if ((unsigned)js >= (unsigned)n_src_total) jj = js < 0 ? 0 : n_src_total - 1;
         double y = (double)src[((size_t)pl * src_rows_local + (size_t)(jj - src_y0)) * width + i], fw = pf[k];
         sum += fw * y;
-        wsum += fw;
+        if (!T.uniform) wsum += fw;
     }
+    if (T.uniform) wsum = T.wsum_uniform;
     if (wsum != 0.0) sum /= wsum;
     dst[(size_t)pl * dst_plane_stride + (size_t)j * width + i] = (float)sum;
 }

@@ -95,4 +95,5 @@ typedef struct RtTapTable {     /* ComputeTaps / Resample, Sampling.cpp:86-184 *
     const int    *first, *count, *offset;
     int           uniform;      /* every destination has the same number of taps with bit-identical values (integer ratios) */
     int           max_count;
+    double        wsum_uniform; /* uniform: the sum of the taps in tap order (what every destination's own running sum comes to, Sampling.cpp:171) */
 } RtTapTable;
