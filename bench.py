@@ -77,12 +77,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    # rehearsal of the N > 1 path on a one-GPU box (tools, not the driver): every rank on cuda:0, gloo instead of RCCL
+    rehearse = os.environ.get("RT_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     for kv in filter(None, args.opts.split(",")):
         name, val = kv.split("=")
@@ -140,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     note("timed steps done")
     rt.rt_lib().rt_set_option(b"time_kernels", 0)
-    tot = torch.tensor([float(rays), float(samples), dt, t_trace], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rays), float(samples), dt, t_trace], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -155,7 +162,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64, configs[3] when MESH10M)" % (scene_name, W, H, spp),
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
-                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows},
+                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows,
+                       **({"rehearsal": "all ranks on one GPU, gloo"} if rehearse else {})},
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])

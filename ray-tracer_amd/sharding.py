@@ -63,9 +63,11 @@ def gather_bands(planes, bands, rank, world, dist):
     row0, row1 = bands[rank], bands[rank + 1]
     slab = torch.zeros((planes.shape[0], maxrows, planes.shape[2]), dtype=planes.dtype, device=planes.device)
     slab[:, : row1 - row0, :] = planes[:, row0:row1, :]
+    if slab.is_cuda and dist.get_backend() == "gloo":      # one-GPU rehearsals: gloo gathers host tensors
+        slab = slab.cpu()
     out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
     dist.gather(slab, out, dst=0)
     if rank == 0:
         for r in range(world):
-            planes[:, bands[r]:bands[r + 1], :] = out[r][:, : bands[r + 1] - bands[r], :]
+            planes[:, bands[r]:bands[r + 1], :] = out[r][:, : bands[r + 1] - bands[r], :].to(planes.device)
     return planes
