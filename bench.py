@@ -4,7 +4,9 @@
 A "step" is one RayTracer::Render of the workload: sample generation, camera rays, CSG intersection,
 shading with shadow / secondary rays and reconstruction, with the scene already resident in HBM and the
 image left in HBM (rt_render_device).  At N > 1 the image rows are split across ranks (no data-path
-collective; the finished row bands are gathered to rank 0 with RCCL, inside the timed region).
+collective; the finished row bands are gathered to rank 0 with RCCL inside the timed region -- the gather of frame
+k is queued asynchronously and runs beside the render of frame k + 1 into a second buffer; the last one is waited
+for before the clock stops).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S0|S1|S2|S4|S4@t|MESH100K|MESH1M|MESH10M|"(scene ...)"] [--width W --height H --spp S]
                   [--no-cpu-baseline]
@@ -113,13 +115,25 @@ def main():
     else:
         rows = sh.row_bands(H, world)
     row0, row1 = rows[rank], rows[rank + 1]
-    planes = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+    # two frame buffers: the gather of frame k (RCCL, its own stream) runs beside the render of frame k + 1
+    frames = [torch.zeros((3, H, W), dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
     stream = torch.cuda.current_stream().cuda_stream
+    state = {"k": 0, "pending": None}
 
     def step():
+        planes = frames[state["k"] % len(frames)]
+        state["k"] += 1
         st = gs.render_device(W, H, spp, planes.data_ptr(), stream, row0, row1 if world > 1 else 0)
-        sh.gather_bands(planes, rows, rank, world, dist)
+        g = sh.gather_bands_async(planes, rows, rank, world, dist)
+        if state["pending"] is not None:
+            state["pending"].finish()       # the previous frame is complete on rank 0 from here on
+        state["pending"] = g
         return st
+
+    def drain():
+        if state["pending"] is not None:
+            state["pending"].finish()
+            state["pending"] = None
 
     def barrier():
         if world > 1:
@@ -128,6 +142,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     note("warmup done")
     rt.rt_lib().rt_set_option(b"time_kernels", 1)      # HIP events around every k_visual launch of the timed region
     barrier()
@@ -142,6 +157,7 @@ def main():
         rays += st.rays()
         samples += st.samples
         t_trace += st.seconds_trace
+    drain()                 # the last frame's gather belongs to the timed region
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0

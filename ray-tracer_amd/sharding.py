@@ -53,6 +53,44 @@ def plan_rows(rt_lib, desc_cls, sampler, width, height, spp, row0, row1):
     return dict(zip(keys, list(out)))
 
 
+class PendingGather:
+    """A band gather in flight (gather_bands_async).  finish() waits for it and, on rank 0, puts the bands in place."""
+
+    def __init__(self, planes, bands, rank, world, work, out, slab=None):
+        self.planes, self.bands, self.rank, self.world, self.work, self.out = planes, bands, rank, world, work, out
+        self.slab = slab                # kept alive until the collective has read it
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()            # RCCL: the current stream waits for the collective; gloo: the host does
+            self.work = None
+        self.slab = None
+        if self.rank == 0 and self.out is not None:
+            for r in range(self.world):
+                n = self.bands[r + 1] - self.bands[r]
+                self.planes[:, self.bands[r]:self.bands[r + 1], :] = self.out[r][:, :n, :].to(self.planes.device)
+            self.out = None
+        return self.planes
+
+
+def gather_bands_async(planes, bands, rank, world, dist):
+    """gather_bands without waiting: the collective is queued behind the work already on the current stream (the band's
+    render) and runs beside whatever is queued next -- the following frame's render into ANOTHER buffer.  The caller
+    calls finish() on the returned object before it reads planes on rank 0 or reuses the buffer."""
+    import torch
+    if world == 1:
+        return PendingGather(planes, bands, rank, world, None, None)
+    maxrows = max(bands[r + 1] - bands[r] for r in range(world))
+    row0, row1 = bands[rank], bands[rank + 1]
+    slab = torch.zeros((planes.shape[0], maxrows, planes.shape[2]), dtype=planes.dtype, device=planes.device)
+    slab[:, : row1 - row0, :] = planes[:, row0:row1, :]
+    if slab.is_cuda and dist.get_backend() == "gloo":      # one-GPU rehearsals: gloo gathers host tensors
+        slab = slab.cpu()
+    out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+    work = dist.gather(slab, out, dst=0, async_op=True)
+    return PendingGather(planes, bands, rank, world, work, out, slab)
+
+
 def gather_bands(planes, bands, rank, world, dist):
     """planes: torch tensor [3][H][W] whose rows bands[rank]:bands[rank+1] this rank has rendered.  After the call
     rank 0's planes holds every band.  One torch.distributed.gather (RCCL on GPUs, gloo on CPU) of equal-size slabs."""

@@ -32,8 +32,19 @@ def _worker(rank, world, port, height, width, q):
         mine = torch.zeros((3, height, width), dtype=torch.float32)
         mine[:, bands[rank]:bands[rank + 1], :] = torch.from_numpy(full[:, bands[rank]:bands[rank + 1], :])
         rt.sharding.gather_bands(mine, bands, rank, world, dist)
+        ok = bool(np.array_equal(mine.numpy(), full)) if rank == 0 else True
+        # the pipelined form bench.py uses: two frames in flight, finish() of frame k after frame k + 1 was queued
+        frames = []
+        for k in range(2):
+            f = torch.zeros((3, height, width), dtype=torch.float32)
+            f[:, bands[rank]:bands[rank + 1], :] = torch.from_numpy(full[:, bands[rank]:bands[rank + 1], :]) * float(k + 1)
+            frames.append(f)
+        g0 = rt.sharding.gather_bands_async(frames[0], bands, rank, world, dist)
+        g1 = rt.sharding.gather_bands_async(frames[1], bands, rank, world, dist)
+        g0.finish(); g1.finish()
         if rank == 0:
-            q.put(bool(np.array_equal(mine.numpy(), full)))
+            ok = ok and bool(np.array_equal(frames[0].numpy(), full)) and bool(np.array_equal(frames[1].numpy(), full * np.float32(2.0)))
+            q.put(ok)
     finally:
         dist.destroy_process_group()
 
