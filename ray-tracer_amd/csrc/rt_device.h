@@ -26,6 +26,7 @@
 #define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
 #define RT_MAX_CAND         64      /* children of one union region whose boxes a ray may touch */
 #define RT_MAX_REGION_DEPTH 4       /* nested union regions */
+#define RT_TILE_CAND        8       /* children of the root region listed per sampling tile (k_tile_mask) */
 #define RT_REGION_MIN       4       /* unions of fewer children stay plain binary code */
 
 enum RtOp {
@@ -227,4 +228,5 @@ typedef struct RtDevScene {
     const RtMeshInfo *meshes;
     const RtMeshNode *mesh_nodes;
     const RtMeshTri  *mesh_tris;
+    const RtBox      *region_child_boxes;   /* parallel to region_child_pc */
 } RtDevScene;

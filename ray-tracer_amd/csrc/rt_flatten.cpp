@@ -501,6 +501,19 @@ struct Flattener {
         }
         rg.child_pc0 = (int)o.region_child_pc.size();
         o.region_child_pc.resize(o.region_child_pc.size() + K, -1);
+        {
+            RtBox zero;
+            memset(&zero, 0, sizeof zero);
+            o.region_child_boxes.resize(o.region_child_pc.size(), zero);
+            for (int k = 0; k < K; k++) {
+                if (boxes[k].empty || !boxes[k].finite()) continue;
+                RtBox &rb = o.region_child_boxes[rg.child_pc0 + k];
+                for (int d = 0; d < 3; d++) {           /* the padding of a BVH leaf (build_bvh_once) */
+                    double e = 1e-6 * (fabs(boxes[k].hi[d] - boxes[k].lo[d]) + fabs(boxes[k].lo[d]) + fabs(boxes[k].hi[d])) + 1e-9;
+                    rb.lo[d] = boxes[k].lo[d] - e; rb.hi[d] = boxes[k].hi[d] + e;
+                }
+            }
+        }
         int ri = (int)o.regions.size();
         o.regions.push_back(rg);
         push(OP_REGION, ri, 0, tag);

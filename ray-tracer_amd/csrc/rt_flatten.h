@@ -19,6 +19,7 @@ struct RtFlatScene {
     std::vector<RtBvhNode>     bvh;
     std::vector<RtChain>       chains;
     std::vector<int32_t>       region_child_pc, region_always, region_lca;
+    std::vector<RtBox>         region_child_boxes;     /* parallel to region_child_pc: the child's padded world box as its BVH leaf holds it */
     std::vector<RtMeshInfo>    meshes;
     std::vector<RtMeshNode>    mesh_nodes;
     std::vector<RtMeshTri>     mesh_tris;

@@ -244,7 +244,7 @@ RT_DEV bool cone_may_touch(const D3 &o, const D3 &d /*unit*/, double cos_t, doub
     const double cos_a = dot(v, d) / dist;              /* angle between the axis and the centre of the sphere */
     return cos_a >= cos_b * cos_t - sin_b * sin_t - 1e-9;       /* a <= b + t, with b + t < pi */
 }
-__global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSampleGrid g, unsigned char *mask)
+__global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSampleGrid g, unsigned char *mask, unsigned short *cand)
 {
     const RtDevScene &S = Sv;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,30 +268,44 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
     if (!(cos_t > 0.0)) { mask[t] = 1; return; }        /* absurdly wide tile: no statement */
     const double sin_t = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
     grow *= 1.0 + 1e-6;
-    bool touch = false;
-    if (S.root_cull == 2) touch = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi);
+    /* 0 = nothing can be touched; 1..RT_TILE_CAND = that many root-region children listed in cand (all of them, ascending);
+       255 = something can be touched, no list */
+    int n = 0;
+    bool walk = false;
+    unsigned short list[RT_TILE_CAND];
+    if (S.root_cull == 2) walk = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi);
     else if (S.root_cull == 1) {
         const RtRegion &rg = S.regions[S.root_cull_arg];
-        if (rg.n_always > 0) touch = true;
+        if (rg.n_always > 0) walk = true;
         else if (rg.bvh_root >= 0) {
             int stack[RT_BVH_STACK], sp = 0, node = rg.bvh_root;
             for (;;) {
                 const RtBvhNode &nd = S.bvh[node];
-                for (int k = 0; k < 4 && !touch; k++) {
+                for (int k = 0; k < 4 && !walk; k++) {
                     if (nd.child[k] == RT_BVH_EMPTY) continue;
                     const double lo[3] = { nd.lo[0][k], nd.lo[1][k], nd.lo[2][k] }, hi[3] = { nd.hi[0][k], nd.hi[1][k], nd.hi[2][k] };
                     if (!cone_may_touch(rc.org, dc, cos_t, sin_t, grow, lo, hi)) continue;
-                    if (nd.child[k] < 0) touch = true;
-                    else if (sp < RT_BVH_STACK) stack[sp++] = nd.child[k];
-                    else touch = true;
+                    if (nd.child[k] < 0) {
+                        if (n < RT_TILE_CAND && cand) list[n++] = (unsigned short)(~nd.child[k]);
+                        else walk = true;
+                    } else if (sp < RT_BVH_STACK) stack[sp++] = nd.child[k];
+                    else walk = true;
                 }
-                if (touch || sp == 0) break;
+                if (walk || sp == 0) break;
                 node = stack[--sp];
             }
         }
     } else
-        touch = true;
-    mask[t] = touch ? 1 : 0;
+        walk = true;
+    if (walk) { mask[t] = 255; return; }
+    for (int i = 1; i < n; i++) {               /* ascending = the reference's evaluation order */
+        unsigned short v = list[i];
+        int j = i - 1;
+        for (; j >= 0 && list[j] > v; --j) list[j + 1] = list[j];
+        list[j + 1] = v;
+    }
+    for (int i = 0; i < n; i++) cand[(size_t)t * RT_TILE_CAND + i] = list[i];
+    mask[t] = (unsigned char)n;
 }
 
 /* the auxiliary dimensions of root sample k that later stages can ask for */
@@ -362,10 +376,19 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         if (k < n) {
             k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
-            const bool masked = g.tile_mask && !rays_org && g.tile_mask[(first + k) / RT_BLUE_N] == 0;
+            const int64_t tile = (first + k) / RT_BLUE_N;
+            const int tm = (g.tile_mask && !rays_org) ? (int)g.tile_mask[tile] : 255;
+            const bool masked = tm == 0;
             if (!masked) {
                 const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
-                keep = scene_may_hit(S, lds, r, RT_INFINITY);
+                if (tm != 255 && g.tile_cand) {
+                    /* the tile's list holds every child a ray through the tile can touch: test their boxes, no BVH walk */
+                    const CullRay cr = cull_ray(r, RT_INFINITY);
+                    const RtBox *cb = S.region_child_boxes + S.regions[S.root_cull_arg].child_pc0;
+                    const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
+                    for (int q = 0; q < tm && !keep; q++) keep = cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr);
+                } else
+                    keep = scene_may_hit(S, lds, r, RT_INFINITY);
             }
             if (!keep && !(masked && g.mask_skips_rgb)) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }

@@ -75,6 +75,10 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     /* FASTBLUE: one byte per traced tile (tx * tiles_y_local + local ty), 0 = no ray through the tile can touch a box of
        the scene (k_tile_mask): k_generate_cull finishes its 1600 samples without generating them.  Null = not used. */
     const unsigned char *tile_mask;
+    /* with the mask: tile_mask[t] = n in 1..RT_TILE_CAND means tile_cand[t * RT_TILE_CAND + 0..n-1] are ALL the children
+       of the root union region (ascending) whose box a ray through the tile can touch, so such a ray is tested against
+       those boxes instead of walking the BVH; 255 = too many or not applicable: walk.  Null = no lists. */
+    const unsigned short *tile_cand;
     /* FASTBLUE: the order in which the 1600 samples of a tile are TRACED: sorted by the 8x8-sample cell of the tile they
        fall into (25 cells of about 64 samples), so that the 64 rays of a wave come from one or two neighbouring cells
        instead of from all over the tile.  Which sample a work item is changes, nothing else does: results are stored
