@@ -121,6 +121,9 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    next to the chain records when they fit; takes effect at rt_scene_upload),
    "tile_mask" (0/1: a pre-pass marks the sampling tiles no ray of which can touch a box of the scene; their samples end
    without being generated),
+   "tile_cand" (0/1/2, default 2: the same pass lists, per tile, the children of the root union region a ray through the
+   tile can touch -- up to 8; 1: the generator tests those boxes instead of walking the BVH per sample, 2: so does the
+   tracing kernel for primary rays; results do not depend on it),
    "full_waves" (1 / 2, default 2: waves per SIMD the kernels for the rare features -- tori, meshes, textures,
    propagators, spectral metals -- are built for; two hide the latency of mesh walks, one has no register spills; at
    rt_scene_upload),

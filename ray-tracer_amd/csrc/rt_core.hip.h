@@ -832,7 +832,7 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_packed, RtDevSc
 {
     extern __shared__ double rt_dyn_lds[];
     SceneLds L;
-    const int groups = n_chains_packed >> 24;
+    const int groups = (n_chains_packed >> 24) & 3;         /* bit 28 belongs to k_visual (primary level) */
     L.n_nodes = S.n_bvh_lds;
     L.n_chains = n_chains_packed & 0xFFFFFF;
     L.stride = blockDim.x;
@@ -956,7 +956,8 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
    The split keeps the common kernels small enough for several waves per SIMD. */
 template <bool LITE, bool CH_LDS = false>
-__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start)
+__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
+                               const unsigned short *tile_list = 0, int tile_n = 0)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
     RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 }, saved[RT_MAX_REGION_DEPTH];
@@ -1070,7 +1071,18 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             uint16_t *cd = cands[nrf];
             int ov = 0;
             PROF_BEGIN(tb);
-            const int nc = region_candidates(S, L, rg, cr, cd, ov);
+            int nc;
+            if (tile_list && nrf == 0 && S.root_cull == 1 && in.a == S.root_cull_arg) {
+                /* a primary ray whose sampling tile came with the complete list of root-region children it can touch
+                   (k_tile_mask): their boxes -- the very boxes the BVH's leaves hold -- are tested directly, ascending */
+                const RtBox *cb = S.region_child_boxes + rg.child_pc0;
+                nc = 0;
+                for (int q = 0; q < tile_n; q++) {
+                    const int c = tile_list[q];
+                    if (cull_box_hit(cb[c].lo, cb[c].hi, cr)) cd[nc++] = (uint16_t)c;
+                }
+            } else
+                nc = region_candidates(S, L, rg, cr, cd, ov);
             PROF_END(A, 1, tb);
             A.overflow |= ov;
             if (nc == 0) { pc = rg.end_pc; break; }

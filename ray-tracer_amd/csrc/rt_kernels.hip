@@ -496,7 +496,14 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         aux_load<LITE>(S, P, root, aux);
         Arena A;
         int start;
-        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start);
+        const unsigned short *tile_list = 0;
+        int tile_n = 0;
+        if (((n_chains_lds >> 28) & 1) && P.tile_n) {           /* bit 28: these are the chunk's primary rays */
+            const int64_t tile = (P.tile_first + root) / RT_BLUE_N;
+            const int m = P.tile_n[tile];
+            if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
+        }
+        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF

@@ -51,6 +51,11 @@ typedef struct RtPipe {
     float  *s_E;                /* 10 */
     int    *slow_v, *slow_s;    /* frames / shadow rays the LITE kernels handed to the FULL ones: fcap, scap */
     int    *counters;           /* CTR_COUNT */
+    /* the sampling tiles' candidate lists (RtSampleGrid::tile_mask / tile_cand) for the PRIMARY rays of this chunk: root
+       sample k of the chunk lies in tile (tile_first + k) / 1600.  Null = none. */
+    const unsigned char  *tile_n;
+    const unsigned short *tile_cand;
+    int64_t               tile_first;
 } RtPipe;
 
 typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
