@@ -634,3 +634,25 @@ def test_bad_arguments_are_errors_not_crashes(gpu):
         gpu.GpuScene(f9.desc)
     img, st = g.render(8, 8, 4)                      # the handle is still usable after the failures
     assert st.samples > 0 and np.isfinite(img).all()
+
+
+@pytest.mark.parametrize("scene", ["S0", SCENE_ROW, SCENE_FOG_PERSPECTIVE])
+def test_tile_candidate_lists_are_invisible(gpu, scene):
+    """The per-tile lists of root-region children (tile_cand: 1 = the generator culls against them, 2 = primary rays take
+    their candidates from them) replace BVH walks and nothing else: frames, bands and ray counts equal those without
+    lists, at sizes where tiles see one or two children (lists) and where they see dozens (fallback to the BVH)."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    try:
+        for (w, h, spp, r0, r1) in ((640, 360, 16, 0, 0), (640, 360, 16, 100, 223), (48, 27, 1, 0, 0), (200, 200, 4, 0, 0)):
+            L.rt_set_option(b"tile_cand", 0)
+            ref, sr = g.render(w, h, spp, row0=r0, row1=r1)
+            for mode in (1, 2):
+                L.rt_set_option(b"tile_cand", mode)
+                a, sa = g.render(w, h, spp, row0=r0, row1=r1)
+                assert np.array_equal(a, ref), (w, h, spp, mode)
+                assert sa.rays() == sr.rays() and sa.samples == sr.samples
+            assert ref.max() > 0
+    finally:
+        L.rt_set_option(b"tile_cand", 2)
