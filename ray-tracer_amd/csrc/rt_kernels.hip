@@ -308,6 +308,23 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
     mask[t] = (unsigned char)n;
 }
 
+/* need[t] = some tile within D tiles of t (Chebyshev) is not masked */
+__global__ void __launch_bounds__(256) k_tile_need(const unsigned char *mask, unsigned char *need, int tiles_x, int tiles_y, int D)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const int tx = t / tiles_y, ty = t - tx * tiles_y;
+    unsigned char any = 0;
+    for (int x = tx - D; x <= tx + D && !any; x++) {
+        if (x < 0 || x >= tiles_x) continue;
+        for (int y = ty - D; y <= ty + D; y++) {
+            if (y < 0 || y >= tiles_y) continue;
+            if (mask[x * tiles_y + y]) { any = 1; break; }
+        }
+    }
+    need[t] = any;
+}
+
 /* the auxiliary dimensions of root sample k that later stages can ask for */
 RT_DEV void aux_store(const RtDevScene &S, const RtPipe &P, int k, const double *aux)
 {
@@ -1046,8 +1063,13 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
     int px = blockIdx.x * blockDim.x + threadIdx.x;
     int py = y0 + blockIdx.y;
     if (px >= g.nW || py >= y1) return;
-    float r, gg, b, w;
-    splat_pixel(Sv, g, T, sample_rgb, px, py, r, gg, b, w);
+    float r = 0.0f, gg = 0.0f, b = 0.0f, w = 0.0f;
+    bool needed = true;
+    if (g.tile_need) {
+        const int tx = px / RT_BLUE_NSQRT, ty = py / RT_BLUE_NSQRT - g.tile_y0;
+        if (tx < g.tiles_x && ty >= 0 && ty < g.tiles_y_local) needed = g.tile_need[tx * g.tiles_y_local + ty] != 0;
+    }
+    if (needed) splat_pixel(Sv, g, T, sample_rgb, px, py, r, gg, b, w);
     size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
     im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b;
     wt2[o] = w;

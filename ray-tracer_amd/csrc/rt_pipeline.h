@@ -84,6 +84,10 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
        of the root union region (ascending) whose box a ray through the tile can touch, so such a ray is tested against
        those boxes instead of walking the BVH; 255 = too many or not applicable: walk.  Null = no lists. */
     const unsigned short *tile_cand;
+    /* FASTBLUE reconstruction: one byte per traced tile, 0 = no supersample pixel of the tile can matter: every output
+       pixel whose filter support reaches it sees black samples only, so its value is 0 whatever the weights are
+       (k_tile_need: the mask dilated by twice the filter's reach).  k_splat_gather writes zeros there.  Null = all needed. */
+    const unsigned char *tile_need;
     /* FASTBLUE: the order in which the 1600 samples of a tile are TRACED: sorted by the 8x8-sample cell of the tile they
        fall into (25 cells of about 64 samples), so that the 64 rays of a wave come from one or two neighbouring cells
        instead of from all over the tile.  Which sample a work item is changes, nothing else does: results are stored

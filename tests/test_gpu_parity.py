@@ -654,5 +654,11 @@ def test_tile_candidate_lists_are_invisible(gpu, scene):
                 assert np.array_equal(a, ref), (w, h, spp, mode)
                 assert sa.rays() == sr.rays() and sa.samples == sr.samples
             assert ref.max() > 0
+            # the splat gather's skip of supersample pixels that cannot matter (tile_need)
+            L.rt_set_option(b"tile_need", 0)
+            b, sb = g.render(w, h, spp, row0=r0, row1=r1)
+            L.rt_set_option(b"tile_need", 1)
+            assert np.array_equal(b, ref) and sb.rays() == sr.rays()
     finally:
         L.rt_set_option(b"tile_cand", 2)
+        L.rt_set_option(b"tile_need", 1)
