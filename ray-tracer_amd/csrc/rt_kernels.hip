@@ -1295,7 +1295,20 @@ __global__ void __launch_bounds__(256) k_adapt_direct(const float *im2, const fl
 #define RT_RS_SPAN  4608        /* floats of source per workgroup that fit the staging buffer */
 #define RT_RS_TAPS  520
 #define RT_RS_IDX(j) ((j) + ((j) >> 5))
-__global__ void __launch_bounds__(256) k_resample_rows(const float *src, int planes, int rows, int n_src, int n_dst, RtTapTable T, float *dst)
+/* need (optional, FastBlue): RtSampleGrid::tile_need with its geometry.  A destination all of whose source pixels lie in
+   tiles that cannot matter reads zeros only: the zero it would compute (+0 / wsum) is written without the tap loop. */
+struct RtNeedMap { const unsigned char *need; int tiles_x, tiles_y_local, tile_row0 /* tile_y0 * 40 - src_y0: local source row where tile row 0 begins */; };
+RT_DEV bool need_any(const RtNeedMap &nd, int x0, int x1, int n_src, int ty0, int ty1)
+{
+    if (ty0 < 0 || ty1 >= nd.tiles_y_local) return true;
+    const int a = (x0 < 0 ? 0 : x0) / RT_BLUE_NSQRT, b = (x1 >= n_src ? n_src - 1 : x1) / RT_BLUE_NSQRT;
+    for (int tx = a; tx <= b; tx++) {
+        if (tx >= nd.tiles_x) return true;
+        for (int ty = ty0; ty <= ty1; ty++) if (nd.need[tx * nd.tiles_y_local + ty]) return true;
+    }
+    return false;
+}
+__global__ void __launch_bounds__(256) k_resample_rows(const float *src, int planes, int rows, int n_src, int n_dst, RtTapTable T, float *dst, RtNeedMap nd)
 {
     __shared__ float  s_src[RT_RS_SPAN + RT_RS_SPAN / 32 + 2];
     __shared__ double s_taps[RT_RS_TAPS];
@@ -1319,6 +1332,10 @@ __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int pla
     __syncthreads();
     if (id >= n_dst) return;
     const int i0 = T.first[id], cnt = T.count[id];
+    if (nd.need && T.uniform && cnt > 0 && row >= nd.tile_row0) {
+        const int ty = (row - nd.tile_row0) / RT_BLUE_NSQRT;
+        if (!need_any(nd, i0, i0 + cnt - 1, n_src, ty, ty)) { dst[((size_t)pl * rows + row) * n_dst + id] = 0.0f; return; }
+    }
     const double *pf = T.taps + T.offset[id];
     double sum = 0.0, wsum = 0.0;
     if (staged && utaps) {
@@ -1398,13 +1415,22 @@ __global__ void __launch_bounds__(256) k_splat_resample_rows(const RtDevScene Sv
 
 /* vertical pass: src [planes][src_rows_local][width] (rows src_y0..), dst rows [row0,row1) of [planes][H][width] */
 __global__ void __launch_bounds__(256) k_resample_cols(const float *src, int planes, int src_rows_local, int src_y0, int n_src_total, int width,
-                                                       int row0, int row1, RtTapTable T, float *dst, size_t dst_plane_stride)
+                                                       int row0, int row1, RtTapTable T, float *dst, size_t dst_plane_stride,
+                                                       RtNeedMap nd, const int *first_x, const int *count_x, int n_src_x)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int j = row0 + blockIdx.y;
     int pl = blockIdx.z;
     if (i >= width || j >= row1 || pl >= planes) return;
     int j0 = T.first[j], cnt = T.count[j];
+    if (nd.need && T.uniform && cnt > 0) {
+        /* the row-pass values this destination reads come from supersample pixels [first_x[i], +count_x[i]) of rows [j0, j0 + cnt) */
+        const int ya = (j0 < 0 ? 0 : j0) - src_y0, yb = (j0 + cnt - 1 >= n_src_total ? n_src_total - 1 : j0 + cnt - 1) - src_y0;
+        if (ya >= nd.tile_row0 && !need_any(nd, first_x[i], first_x[i] + count_x[i] - 1, n_src_x, (ya - nd.tile_row0) / RT_BLUE_NSQRT, (yb - nd.tile_row0) / RT_BLUE_NSQRT)) {
+            dst[(size_t)pl * dst_plane_stride + (size_t)j * width + i] = 0.0f;
+            return;
+        }
+    }
     const double *pf = T.taps + T.offset[j];
     double sum = 0.0, wsum = 0.0;
     for (int k = 0; k < cnt; k++) {

@@ -654,11 +654,12 @@ def test_tile_candidate_lists_are_invisible(gpu, scene):
                 assert np.array_equal(a, ref), (w, h, spp, mode)
                 assert sa.rays() == sr.rays() and sa.samples == sr.samples
             assert ref.max() > 0
-            # the splat gather's skip of supersample pixels that cannot matter (tile_need)
-            L.rt_set_option(b"tile_need", 0)
-            b, sb = g.render(w, h, spp, row0=r0, row1=r1)
-            L.rt_set_option(b"tile_need", 1)
-            assert np.array_equal(b, ref) and sb.rays() == sr.rays()
+            # reconstruction's skip of what cannot matter (tile_need: 1 = the splat gather, 2 = the resampling passes too)
+            for mode in (0, 1):
+                L.rt_set_option(b"tile_need", mode)
+                b, sb = g.render(w, h, spp, row0=r0, row1=r1)
+                assert np.array_equal(b, ref) and sb.rays() == sr.rays(), (w, h, spp, mode)
+            L.rt_set_option(b"tile_need", 2)
     finally:
         L.rt_set_option(b"tile_cand", 2)
-        L.rt_set_option(b"tile_need", 1)
+        L.rt_set_option(b"tile_need", 2)
