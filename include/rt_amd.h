@@ -121,6 +121,8 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    next to the chain records when they fit; takes effect at rt_scene_upload),
    "tile_mask" (0/1: a pre-pass marks the sampling tiles no ray of which can touch a box of the scene; their samples end
    without being generated),
+   "alt_chain" (0/1, default 1: a primary ray whose sampling tile lists a single child of the root region, a bare
+   chain, runs that chain alone instead of the region; at rt_scene_upload; results do not depend on it),
    "tile_need" (0/1/2, default 2: FastBlue reconstruction skips the supersample pixels of tiles farther than twice the
    filter's reach from every tile that can hold a coloured sample -- every output pixel that could read them is 0 whatever
    they hold -- in the splat gather (1) and in the two resampling passes (2); results do not depend on it),

@@ -978,6 +978,17 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     A.prof[7] = (int)(clock64() - t_cr);
 #endif
     int pc = 0;
+    if (tile_list && tile_n == 1 && S.n_root_alt > 0) {
+        /* the sampling tile of this primary ray can touch ONE child of the root region: if that is a bare chain, its
+           box is tested here and the chain runs alone, for the root consumer (what the region would have made of it) */
+        const int c = tile_list[0];
+        const int apc = S.root_alt_pc[c];
+        if (apc >= 0) {
+            const RtBox &cb = S.region_child_boxes[S.root_child_pc0 + c];
+            if (!cull_box_hit(cb.lo, cb.hi, cr)) goto done;
+            pc = apc;
+        }
+    }
     for (;;) {
         const RtInstr in = S.prog[pc];
         pc++;

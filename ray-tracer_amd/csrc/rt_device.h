@@ -229,4 +229,6 @@ typedef struct RtDevScene {
     const RtMeshNode *mesh_nodes;
     const RtMeshTri  *mesh_tris;
     const RtBox      *region_child_boxes;   /* parallel to region_child_pc */
+    const int32_t    *root_alt_pc;          /* root_cull == 1: per child of the root region, pc of "that chain for the root consumer; OP_END" behind the program, -1 = the child is not a bare chain */
+    int32_t           n_root_alt, root_child_pc0;
 } RtDevScene;

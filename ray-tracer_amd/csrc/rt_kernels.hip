@@ -983,6 +983,7 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
     const CullRay cr = cull_ray(ray, RT_INFINITY);
     for (int pc = 0; pc < S.n_prog; pc++) {
         int op = S.prog[pc].op;
+        if (op == OP_END) break;            /* behind it: the single-chain shortcuts of the root region (RtDevScene::root_alt_pc) */
         bool hit = true;
         if (op == OP_CHAIN) {
             int b = S.chains[S.prog[pc].a].box;
