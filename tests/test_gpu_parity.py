@@ -663,3 +663,21 @@ def test_tile_candidate_lists_are_invisible(gpu, scene):
     finally:
         L.rt_set_option(b"tile_cand", 2)
         L.rt_set_option(b"tile_need", 2)
+
+
+def test_single_candidate_shortcut_is_invisible(gpu):
+    """alt_chain: primary rays whose sampling tile lists one bare-chain child of the root region run that chain alone.
+    Scenes uploaded with and without the shortcut render the same frames (sizes where most tiles list one child)."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene("S0", "fastblue", optimize=True)
+    try:
+        L.rt_set_option(b"alt_chain", 0)
+        ref_scene = gpu.GpuScene(fs.desc)
+        L.rt_set_option(b"alt_chain", 1)
+        alt_scene = gpu.GpuScene(fs.desc)
+        for (w, h, spp, r0, r1) in ((960, 540, 16, 0, 0), (960, 540, 16, 200, 333), (256, 256, 64, 0, 0)):
+            a, sa = alt_scene.render(w, h, spp, row0=r0, row1=r1)
+            b, sb = ref_scene.render(w, h, spp, row0=r0, row1=r1)
+            assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0
+    finally:
+        L.rt_set_option(b"alt_chain", 1)
