@@ -955,7 +955,10 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
 /* LITE = true compiles the rare, register-hungry features out (torus quartics here; texture call-outs, propagators
    and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
    The split keeps the common kernels small enough for several waves per SIMD. */
-template <bool LITE, bool CH_LDS = false>
+/* TILES: the caller may pass the candidate list of a primary ray's sampling tile (k_tile_mask).  A template parameter, so
+   that kernels for scenes and levels without such lists are compiled without that code: its few extra live registers
+   cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
+template <bool LITE, bool CH_LDS = false, bool TILES = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0)
 {
@@ -978,7 +981,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     A.prof[7] = (int)(clock64() - t_cr);
 #endif
     int pc = 0;
-    if (tile_list && tile_n == 1 && S.n_root_alt > 0) {
+    if (TILES && tile_list && tile_n == 1 && S.n_root_alt > 0) {
         /* the sampling tile of this primary ray can touch ONE child of the root region: if that is a bare chain, its
            box is tested here and the chain runs alone, for the root consumer (what the region would have made of it) */
         const int c = tile_list[0];
@@ -1083,7 +1086,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             int ov = 0;
             PROF_BEGIN(tb);
             int nc;
-            if (tile_list && nrf == 0 && S.root_cull == 1 && in.a == S.root_cull_arg) {
+            if (TILES && tile_list && nrf == 0 && S.root_cull == 1 && in.a == S.root_cull_arg) {
                 /* a primary ray whose sampling tile came with the complete list of root-region children it can touch
                    (k_tile_mask): their boxes -- the very boxes the BVH's leaves hold -- are tested directly, ascending */
                 const RtBox *cb = S.region_child_boxes + rg.child_pc0;

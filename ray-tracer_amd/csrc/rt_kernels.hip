@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
  * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
 /* MODE: what the workgroup stages in LDS besides the top of the BVH -- 0 nothing, 1 the chain records, 2 the chain records
    and the small scene tables (scene_lds_load); chosen per scene at upload, compiled in so that the loads are LDS loads */
-template <bool LITE, int MODE>
+template <bool LITE, int MODE, bool TILES = false>
 __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
@@ -515,12 +515,12 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         int start;
         const unsigned short *tile_list = 0;
         int tile_n = 0;
-        if (((n_chains_lds >> 28) & 1) && P.tile_n) {           /* bit 28: these are the chunk's primary rays */
+        if constexpr (TILES) {                                  /* launched for the chunk's primary rays only */
             const int64_t tile = (P.tile_first + root) / RT_BLUE_N;
             const int m = P.tile_n[tile];
             if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
         }
-        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n);
+        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
