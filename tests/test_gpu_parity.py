@@ -681,3 +681,21 @@ def test_single_candidate_shortcut_is_invisible(gpu):
             assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0
     finally:
         L.rt_set_option(b"alt_chain", 1)
+
+
+@pytest.mark.parametrize("name,off,on", [("lds_tables", 0, 1), ("lds_chains", 0, 1), ("full_waves", 1, 2), ("full_tables", 0, 1),
+                                         ("cell_order", 0, 1), ("persistent", 0, 1)])
+@pytest.mark.parametrize("scene", ["S0", "S1"])
+def test_launch_and_staging_options_are_invisible(gpu, scene, name, off, on):
+    """The options that only choose where tables live, how kernels are launched or in which order samples are traced
+     do not change a frame: scenes uploaded and rendered with the option off and on."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    try:
+        assert L.rt_set_option(name.encode(), off) == 0
+        a, sa = gpu.GpuScene(fs.desc).render(200, 120, 4)
+        assert L.rt_set_option(name.encode(), on) == 0
+        b, sb = gpu.GpuScene(fs.desc).render(200, 120, 4)
+        assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0
+    finally:
+        L.rt_set_option(name.encode(), on)
