@@ -645,7 +645,9 @@ def test_tile_candidate_lists_are_invisible(gpu, scene):
     fs = gpu.FrontScene(scene, "fastblue", optimize=True)
     g = gpu.GpuScene(fs.desc)
     try:
-        for (w, h, spp, r0, r1) in ((640, 360, 16, 0, 0), (640, 360, 16, 100, 223), (48, 27, 1, 0, 0), (200, 200, 4, 0, 0)):
+        # sample rates: filter reach of 1, 2 and 4 tiles; 2.25 spp has non-uniform taps (only the splat gather skips)
+        for (w, h, spp, r0, r1) in ((640, 360, 16, 0, 0), (640, 360, 16, 100, 223), (48, 27, 1, 0, 0), (200, 200, 4, 0, 0),
+                                    (200, 120, 256, 0, 0), (333, 177, 2.25, 50, 90)):
             L.rt_set_option(b"tile_cand", 0)
             ref, sr = g.render(w, h, spp, row0=r0, row1=r1)
             for mode in (1, 2):
