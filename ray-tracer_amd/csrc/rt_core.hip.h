@@ -960,7 +960,7 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
 template <bool LITE, bool CH_LDS = false, bool TILES = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
-                               const unsigned short *tile_list = 0, int tile_n = 0)
+                               const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
     RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 }, saved[RT_MAX_REGION_DEPTH];
@@ -981,13 +981,14 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     A.prof[7] = (int)(clock64() - t_cr);
 #endif
     int pc = 0;
-    if (TILES && tile_list && tile_n == 1 && S.n_root_alt > 0) {
+    if (TILES && S.n_root_alt > 0 && (tile_one >= 0 || (tile_list && tile_n == 1))) {
         /* the sampling tile of this primary ray can touch ONE child of the root region: if that is a bare chain, its
-           box is tested here and the chain runs alone, for the root consumer (what the region would have made of it) */
-        const int c = tile_list[0];
+           box is tested here and the chain runs alone, for the root consumer (what the region would have made of it).
+           The two table reads do not wait for each other. */
+        const int c = tile_one >= 0 ? tile_one : (int)tile_list[0];
         const int apc = S.root_alt_pc[c];
+        const RtBox cb = S.region_child_boxes[S.root_child_pc0 + c];
         if (apc >= 0) {
-            const RtBox &cb = S.region_child_boxes[S.root_child_pc0 + c];
             if (!cull_box_hit(cb.lo, cb.hi, cr)) goto done;
             pc = apc;
         }

@@ -339,14 +339,17 @@ RT_DEV void aux_load(const RtDevScene &S, const RtPipe &P, int root, double *aux
     if constexpr (!LITE) if (S.aux_tex) { aux[4] = P.aux[(size_t)4 * P.ncap + root]; aux[5] = P.aux[(size_t)5 * P.ncap + root]; }   /* LITE hands textured hits to FULL */
 }
 
-RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const DRay &r, const double *aux)
+/* hint: bits 20..31 of a root frame's flags word = 1 + the ONE child of the root region the sample's tile can touch (0 = no
+   such statement): k_visual<.., TILES> then needs no tile lookups for the ray (FR_HINT_SHIFT, dropped by FR_KEEP_MASK) */
+#define FR_HINT_SHIFT 20
+RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const DRay &r, const double *aux, int hint = 0)
 {
     d3_store(P.f_ray, P.fcap, 0, f, r.org);
     d3_store(P.f_ray, P.fcap, 3, f, r.dir);
     aux_store(S, P, k, aux);
     P.f_parent[f] = -1;
     P.f_root[f] = k;
-    P.f_flags[f] = 0;
+    P.f_flags[f] = (int)((unsigned)hint << FR_HINT_SHIFT);
 }
 
 /* work item k of a chunk -> the sample it traces (RtSampleGrid::fb_order) */
@@ -431,7 +434,12 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         double aux[6];
         DRay r;
         root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
-        root_frame(S, P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux);
+        int hint = 0;
+        if (g.tile_mask && g.tile_cand && !rays_org) {
+            const int64_t tile = (first + k) / RT_BLUE_N;
+            if (g.tile_mask[tile] == 1) { const int c = g.tile_cand[(size_t)tile * RT_TILE_CAND]; if (c < 4095) hint = c + 1; }
+        }
+        root_frame(S, P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux, hint);
     }
 }
 
@@ -505,7 +513,8 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     int flags = 0;
     bool bail = false;
     if (live) {
-        flags = P.f_flags[f] & FR_KEEP_MASK;
+        const int flags_raw = P.f_flags[f];
+        flags = flags_raw & FR_KEEP_MASK;
         DRay ray;
         ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
         ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
@@ -514,13 +523,17 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         Arena A;
         int start;
         const unsigned short *tile_list = 0;
-        int tile_n = 0;
+        int tile_n = 0, one = -1;
         if constexpr (TILES) {                                  /* launched for the chunk's primary rays only */
-            const int64_t tile = (P.tile_first + root) / RT_BLUE_N;
-            const int m = P.tile_n[tile];
-            if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
+            const int hint = (int)((unsigned)flags_raw >> FR_HINT_SHIFT);
+            if (hint) one = hint - 1;                           /* the generator has looked the tile up already */
+            else {
+                const int64_t tile = (P.tile_first + root) / RT_BLUE_N;
+                const int m = P.tile_n[tile];
+                if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
+            }
         }
-        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n);
+        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
