@@ -32,7 +32,11 @@ enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * 
        CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
        CTR_COUNT = 10 * CTR_LINE };
 #define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
-#define RT_CLAIM 256        /* items a persistent wave claims per atomic: four 64-item passes */
+#ifndef RT_CLAIM
+#define RT_CLAIM 128        /* items a persistent wave claims per atomic: two 64-item passes.  Same box, 4K / 64 spp: 512 / 256 / 128 / 64 items =
+                               S0 58.2 / 55.8 / 53.5 / 55.7 ms, S2 - / 478 / 471 / 520, S1 350 / 342 / 342 / 345: large claims leave waves idle at the end
+                               of every launch, small ones queue up on the counter */
+#endif
 
 typedef struct RtPipe {
     int     fcap, scap, ncap;   /* frame, shadow-ray and root capacities */
