@@ -111,7 +111,7 @@ void rt_random_skip(uint32_t state_xc[2], uint64_t ndraws);
    k_visual.  out9: 9 doubles. */
 int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out9);
 
-/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 16,776,000 = 10485 sampling tiles),
+/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 33,552,000 = 20970 sampling tiles; the queues of a pass take about 2 KB of HBM per sample),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
    "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
    "fuse_splat" (0/1, default 0: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled
