@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 W_AFFINE, W_QUADRIC, W_BOX, W_MERGE, W_SHADE, W_SHADE_LIGHT = 33.0, 57.0, 30.0, 6.0, 250.0, 60.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = half of the 157.3 TF FP32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
-# PMC measurement of the same workload (a copy of profiles/r01_l_pmc_traffic_k_visual.json kept where GPU runs can read it)
+# PMC measurement of the same workload (a copy of profiles/r01_m_pmc_traffic_k_visual.json kept where GPU runs can read it)
 TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic_k_visual.json")
 
 
