@@ -7,6 +7,10 @@ Bars:
     both sides); tori go through acos/cos/sin in the cubic (device libm) -> 1e-12 relative
   * per-sample RGB and images: relative RMSE <= 1e-6 (only exp() in ColoredGlass and the torus trig
     can differ); scenes without either are required to be bit exact.
+  * triangle meshes (policy Q14): +,-,*,/ only, so hit lists, radiance and frames are bit exact against the oracle's
+    brute force over all triangles, whatever the device's BVH skips.
+  * every acceleration (culling boxes, tile mask, tile candidate lists, reconstruction skips, chunking, LDS staging, launch
+    shapes) has a test that renders with it off and on and compares frames with ==.
 """
 import numpy as np
 import pytest
