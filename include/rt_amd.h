@@ -138,6 +138,8 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    workgroups fit a CU; at rt_scene_upload),
    "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */
 int  rt_set_option(const char *name, int64_t value);
+/* the current value of a tunable, -1 (and rt_last_error) for an unknown name */
+int64_t rt_get_option(const char *name);
 
 #ifdef __cplusplus
 }

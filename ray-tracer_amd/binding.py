@@ -91,6 +91,8 @@ def rt_lib():
         L.rt_build_quasi_index.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.rt_random_unsigned.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.rt_set_option.argtypes = [C.c_char_p, C.c_int64]
+        L.rt_get_option.argtypes = [C.c_char_p]
+        L.rt_get_option.restype = C.c_int64
         _rt = L
     return _rt
 
@@ -226,6 +228,23 @@ class GpuScene:
             self.close()
         except Exception:
             pass
+
+
+OPTION_NAMES = ("chunk_samples", "bvh", "root_cull", "lds_chains", "fuse_splat", "cell_order", "full_tables", "full_waves", "persistent",
+                "lds_tables", "tile_mask", "alt_chain", "tile_need", "tile_cand", "time_kernels")
+
+
+def get_options():
+    """Current values of the library's tunables (rt_get_option)."""
+    L = rt_lib()
+    return {n: int(L.rt_get_option(n.encode())) for n in OPTION_NAMES}
+
+
+def set_options(opts):
+    L = rt_lib()
+    for n, v in opts.items():
+        if L.rt_set_option(n.encode(), int(v)):
+            raise RtError("rt_set_option(%s, %d): %s" % (n, v, L.rt_last_error().decode()))
 
 
 def build_quasi_index(prime, n):

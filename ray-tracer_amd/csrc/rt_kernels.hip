@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
             if (flags & FR_R_ZERO) R = spec_const(0.0f);
             else if (flags & FR_R_AMBIENT) { Spec E = spec_load(S.ambient) * RT_PI; R = spec_const(0.0f); R = R + color * E; }     /* as k_visual would have */
             else R = spec_fetch(P.f_R, P.fcap, f);
-            int k = 0;
+            int k;
             for (int li = 0; li < S.n_lights; li++) {
                 const RtLightDev &l = S.lights[li];
                 D3 lo = d3(l.org[0], l.org[1], l.org[2]);
@@ -840,8 +840,14 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
                 double fNL = dot(cvN, vL);
                 Spec Eraw;
                 if (l.no_shadow) Eraw = spec_div(spec_load(l.flux), 4.0 * RT_PI * dot(dir, dir));      /* Shade.cpp:315-318 */
-                else { Eraw = spec_fetch(P.s_E, P.scap, base + k); k++; }
-                (void)mask;
+                else {
+                    /* the shadow ray k_visual queued for this light: its slot follows from the mask k_visual stored, not
+                       from this loop's own count -- a light k_visual did not queue (it cannot happen while the two
+                       predicates are the same code) contributes nothing instead of shifting the others' slots */
+                    if (!(mask & (1u << li))) continue;
+                    k = __popc(mask & ((1u << li) - 1u));
+                    Eraw = spec_fetch(P.s_E, P.scap, base + k);
+                }
                 Spec E = Eraw * fNL;
                 if (spec_is_black(E)) continue;
                 Spec refl = brdf(rough, luster, color, hn, vL, vE, cvN, F);

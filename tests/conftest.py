@@ -24,6 +24,26 @@ def rt(entry):
     return entry.load_package()
 
 
+@pytest.fixture(autouse=True)
+def _library_defaults(request):
+    """Every GPU test starts from, and leaves behind, the library's shipped tunables: a test that changes one and fails
+    (or restores a wrong value) cannot change what the tests after it exercise."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    import __graft_entry__ as g
+    rt = g.load_package()
+    global _DEFAULTS
+    if _DEFAULTS is None:
+        _DEFAULTS = rt.get_options()       # first GPU test of the session: nothing has been set yet
+    rt.set_options(_DEFAULTS)
+    yield
+    rt.set_options(_DEFAULTS)
+
+
+_DEFAULTS = None
+
+
 @pytest.fixture(scope="session")
 def oracle(entry):
     """CPU oracle binding -- test infrastructure only."""

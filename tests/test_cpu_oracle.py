@@ -62,8 +62,10 @@ def test_oracle_reproduces_reference_checksums_1spp(rt, oracle, case):
     _check_case(rt, oracle, case)
 
 
-@pytest.mark.parametrize("case", [c for c in SURVEY if c["spp"] == 16 and c["scene"] == "S1"], ids=lambda c: "%s_%d_%dspp" % (c["scene"], c["width"], c["spp"]))
+@pytest.mark.parametrize("case", [c for c in SURVEY if c["spp"] == 16], ids=lambda c: "%s_%d_%dspp" % (c["scene"], c["width"], c["spp"]))
 def test_oracle_reproduces_reference_checksums_fastblue(rt, oracle, case):
+    """BASELINE configs[0] exactly (512 x 512, 16 spp FastBlue): S1 (soft shadows, every primitive of the zoo) and S0 (the
+    as-checked-in 257-sphere scene, brute-force union in the oracle as in the reference: about 40 s of CPU on 8 threads)."""
     _check_case(rt, oracle, case)
 
 
