@@ -132,7 +132,7 @@ def test_Q12_recorded_affine_of_a_bare_primitive_is_the_static_one(gpu, oracle):
         assert np.array_equal(x, y)
     back = g.intersect(org[::-1].copy(), dr[::-1].copy(), max_hits=6, transform=1)
     assert np.array_equal(back[2][::-1], gr[2])                          # normals do not depend on the order of the rays
-    assert (gr[0] > 0).mean() > 0.2
+    assert (gr[0] > 0).mean() > 0.1
 
 
 def test_Q13_texture_colour_belongs_to_the_hit(gpu, oracle):
