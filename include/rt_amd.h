@@ -47,6 +47,17 @@ int  rt_render(rt_scene *s, const RtRenderDesc *rd, float *planes, RtStats *stat
    and what a multi-GPU caller gathers with RCCL. */
 int  rt_render_device(rt_scene *s, const RtRenderDesc *rd, float *planes_dev, RtStats *stats, void *hip_stream);
 
+/* rt_render_device for callers that cannot allocate device memory: it has NO counterpart in the reference and exists for
+   code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same image (bit
+   for bit), but every buffer the render needs -- wavefront queues, per-sample colours, reconstruction images, tables -- is
+   carved out of one file-scope device array of rt_static_scratch_size() bytes (128 MiB; each GPU the library runs on holds
+   it until the process ends) instead of being allocated: no hipMalloc / hipFree and no allocating library routine is called.
+   A render whose buffers (about 28 bytes per sample + 2 KB per sample of the smallest pass) do not fit is rejected with
+   RT_ERR_NOMEM and a message that says how much it needs -- render fewer rows per call or use rt_render_device.  Calls on
+   one GPU share that GPU's array: calls that overlap there race.  Option "time_kernels" is ignored. */
+int  rt_render_device_static(rt_scene *s, const RtRenderDesc *rd, float *planes_dev, RtStats *stats, void *hip_stream);
+int64_t rt_static_scratch_size(void);
+
 /* Output stage -- Image::WriteBMP (Image.cpp:416-474): ClampToGamut (Image.cpp:293-327) + GammaEncode (Image.h:206-220)
    against the table of SetGamma (Image.cpp:498-517; gamma = -1.0 is GAMMA_SRGB), 24-bit bottom-up BGR lines.
    rt_bmp_encode: planes HOST float[3][H][W] -> the complete file image (54-byte header of WriteHeaderBMP,

@@ -82,6 +82,8 @@ def rt_lib():
         L.rt_scene_free.argtypes = [C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.POINTER(C.c_float), C.POINTER(RtStats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.c_void_p, C.POINTER(RtStats), C.c_void_p]
+        L.rt_render_device_static.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.c_void_p, C.POINTER(RtStats), C.c_void_p]
+        L.rt_static_scratch_size.restype = C.c_int64
         L.rt_probe_samples.argtypes = [C.c_void_p, C.POINTER(RtRenderDesc), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.rt_probe_camera.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
@@ -179,6 +181,13 @@ class GpuScene:
         rd = RtRenderDesc(width, height, float(spp), row0, row1)
         st = RtStats()
         self._chk(self.L.rt_render_device(self.h, C.byref(rd), C.c_void_p(dev_ptr), C.byref(st), C.c_void_p(stream)), "rt_render_device")
+        return st
+
+    def render_device_static(self, width, height, spp, dev_ptr, stream=0, row0=0, row1=0):
+        """rt_render_device_static: the same render out of the library's static scratch array, no allocation."""
+        rd = RtRenderDesc(width, height, float(spp), row0, row1)
+        st = RtStats()
+        self._chk(self.L.rt_render_device_static(self.h, C.byref(rd), C.c_void_p(dev_ptr), C.byref(st), C.c_void_p(stream)), "rt_render_device_static")
         return st
 
     def samples(self, width, height, spp, first, n):
