@@ -178,7 +178,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64, configs[3] when MESH10M)" % (scene_name, W, H, spp),
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
-                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows,
+                       "rays_per_step": rays_all / args.steps, "rays_fast_per_step": st.rays_fast, "rays_interpreter_level0_per_step": st.rays_visual0,
+                       "parallelism": "rows%d" % world, "bands": rows,
                        **({"rehearsal": "all ranks on one GPU, gloo"} if rehearse else {})},
             "sec_per_frame": dt / args.steps,
         }

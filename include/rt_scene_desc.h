@@ -140,6 +140,8 @@ typedef struct RtStats {
     double  seconds_trace;          /* of which: sample generation + intersect + shading */
     double  seconds_reconstruct;    /* of which: splat + resample + normalise */
     int64_t refined_blocks;         /* AdaptiveBlueSamplingTile: 20x20 blocks that got a second pass (their rays are counted above) */
+    int64_t rays_fast;              /* of rays_primary: traced by k_fast (one chain, hits in registers); GPU only, measurement */
+    int64_t rays_visual0;           /* of rays_primary: traced by k_visual (the interpreter); the rest ended in the generator's cull */
 } RtStats;
 
 #ifdef __cplusplus

@@ -52,7 +52,8 @@ class RtRenderDesc(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("rays_primary", C.c_int64), ("rays_shadow", C.c_int64),
                 ("rays_secondary", C.c_int64), ("hit_overflow", C.c_int64), ("seconds", C.c_double),
-                ("seconds_trace", C.c_double), ("seconds_reconstruct", C.c_double), ("refined_blocks", C.c_int64)]
+                ("seconds_trace", C.c_double), ("seconds_reconstruct", C.c_double), ("refined_blocks", C.c_int64),
+                ("rays_fast", C.c_int64), ("rays_visual0", C.c_int64)]
 
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_secondary
@@ -240,7 +241,7 @@ class GpuScene:
 
 
 OPTION_NAMES = ("chunk_samples", "bvh", "root_cull", "lds_chains", "fuse_splat", "cell_order", "full_tables", "full_waves", "persistent",
-                "lds_tables", "tile_mask", "alt_chain", "tile_need", "tile_cand", "time_kernels")
+                "lds_tables", "tile_mask", "alt_chain", "tile_need", "tile_cand", "time_kernels", "fast_path", "level_sync")
 
 
 def get_options():

@@ -313,8 +313,48 @@ RT_DEV void hit_apply_wraps(const RtChain &ch, HitRec &h)
 /* HitList for solvers that return at most two roots (quadrics, polyhedra, slabs): the same rules as hit_list
    above, written without variable array indices so that the roots and normals stay in registers.
    The list is (optional synthetic t = 0 hit) + (roots >= 0), at most three entries.  With a chain, its wrappers
-   are applied before the records are stored. */
-__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtChain *ch = 0)
+   are applied before the records are handed over.  Where the records go is the emitter's business: ArenaEmit appends a
+   list to the per-lane arena (the interpreter), RegEmit keeps the three records in registers (k_fast, which never
+   instantiates an arena). */
+#ifdef RT_EXP_NONORMAL      /* experiment (wrong pictures): what would hit records without normals be worth? */
+#define HSTORE(dst, src) do { HitRec &d_ = (dst); d_.t = (src).t; d_.leaf_affine = (src).leaf_affine; d_.surf = (src).surf; d_.mat = (src).mat; d_.prim = (src).prim; d_.ntex = (src).ntex; d_.pad_ = 0; d_.texpack = (src).texpack; } while (0)
+#else
+#define HSTORE(dst, src) (dst) = (src)
+#endif
+struct ArenaEmit {
+    Arena &A; int tag;
+    RT_DEV bool begin(int L)
+    {
+        if (A.top + L > RT_ARENA) arena_compact(A);
+        if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return false; }
+        return true;
+    }
+    RT_DEV void put(int i, const HitRec &h) { HSTORE(A.h[A.top + i], h); }
+    RT_DEV void end(int L) { if (L > 0) { list_push(A, A.top, L, tag); A.top += L; } }      /* an empty list is never pushed */
+};
+struct RegEmit {
+    HitRec h0, h1, h2; int L;
+    const double *minv_own;     /* the chain's minv when it alone transforms the hits' normals (RT_CHAIN_OWN_NORMAL), else null */
+    RT_DEV const double *own_minv() const { return minv_own; }
+    RT_DEV bool begin(int) { return true; }
+    RT_DEV void put(int i, const HitRec &h) { if (i == 0) h0 = h; else if (i == 1) h1 = h; else h2 = h; }
+    RT_DEV void end(int n) { L = n; }
+    /* field by field and BY VALUE: a conditional between lvalues selects an address and loads through it, which pins
+       all three records in private memory */
+    template <class T> static RT_DEV T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
+#define RT_SEL3(f) sel3(i, h0.f, h1.f, h2.f)
+    RT_DEV HitRec get(int i) const
+    {
+        HitRec r;
+        r.t = RT_SEL3(t); r.n.x = RT_SEL3(n.x); r.n.y = RT_SEL3(n.y); r.n.z = RT_SEL3(n.z);
+        r.leaf_affine = RT_SEL3(leaf_affine); r.surf = RT_SEL3(surf); r.mat = RT_SEL3(mat); r.prim = RT_SEL3(prim);
+        r.ntex = RT_SEL3(ntex); r.pad_ = 0; r.texpack = RT_SEL3(texpack);
+        return r;
+    }
+#undef RT_SEL3
+};
+template <class Emit>
+RT_DEV void hit_list2_core(Work &w, Emit &out, uint16_t prim, int leaf_affine, const RtChain *ch)
 {
     const int count = w.count;
     const double r0 = WR(w, 0), r1 = WR(w, 1);
@@ -333,16 +373,10 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
     else { t0 = ta; n0 = na; t1 = r1; n1 = WN(w, 1); L = m; }
     if (L >= 2 && t0 == 0.0 && t1 < w.eps) { t0 = t2; n0 = n2; L -= 2; }
     else if (L >= 1 && t0 < w.eps) { t0 = 0.0; n0 = d3(0.0, 0.0, 0.0); }
-    if (L <= 0) return;
-    if (A.top + L > RT_ARENA) arena_compact(A);
-    if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return; }
+    if (L <= 0) { out.end(0); return; }
+    if (!out.begin(L)) return;
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     const int last_in = w.inside_inf ? 1 : 0;
-#ifdef RT_EXP_NONORMAL      /* experiment (wrong pictures): what would hit records without normals be worth? */
-#define HSTORE(dst, src) do { HitRec &d_ = (dst); d_.t = (src).t; d_.leaf_affine = (src).leaf_affine; d_.surf = (src).surf; d_.mat = (src).mat; d_.prim = (src).prim; d_.ntex = (src).ntex; d_.pad_ = 0; d_.texpack = (src).texpack; } while (0)
-#else
-#define HSTORE(dst, src) (dst) = (src)
-#endif
     HitRec h;
     h.leaf_affine = (uint32_t)(leaf_affine + 1); h.prim = prim; h.pad_ = 0;
     {
@@ -350,24 +384,28 @@ __device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_af
         h.mat = (uint16_t)(((L - 1) & 1) ? !last_in : last_in);
         h.surf = (t0 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        HSTORE(A.h[A.top], h);
+        out.put(0, h);
     }
     if (L >= 2) {
         h.t = t1; h.n = n1; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)(((L - 2) & 1) ? !last_in : last_in);
         h.surf = (t1 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        HSTORE(A.h[A.top + 1], h);
+        out.put(1, h);
     }
     if (L >= 3) {
         h.t = t2; h.n = n2; h.ntex = 0; h.texpack = 0;
         h.mat = (uint16_t)last_in;
         h.surf = (t2 > 0.0) ? 1 : 0;
         if (ch) hit_apply_wraps(*ch, h);
-        HSTORE(A.h[A.top + 2], h);
+        out.put(2, h);
     }
-    list_push(A, A.top, L, tag);
-    A.top += L;
+    out.end(L);
+}
+__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtChain *ch = 0)
+{
+    ArenaEmit out = { A, tag };
+    hit_list2_core(w, out, prim, leaf_affine, ch);
 }
 
 /* ClipPlane, Solids.cpp:232-273 */
@@ -476,44 +514,52 @@ RT_DEV bool cull_box_hit(const double *lo, const double *hi, const CullRay &c)
 }
 
 /* ================================================================== primitives */
-__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)     /* Solids.cpp:325-358 */
+RT_DEV void quadric_roots(const double P, const double Q, const double R, const int nclip, const DRay &ray, Work &w)      /* Solids.cpp:325-358 */
 {
-    Work w;
     work_init(w);
     const D3 &d = ray.dir, &o = ray.org;
-    const double P = q.p[0], Q = q.p[1], R = q.p[2];
     double a = d.x * d.x + d.y * d.y + d.z * d.z * P;
     double b = 2.0 * (d.x * o.x + d.y * o.y + d.z * o.z * P) + d.z * Q;
     double c = o.x * o.x + o.y * o.y + o.z * o.z * P + o.z * Q + R;
     w.count = solve_quadratic(&WR(w, 0), a, b, c);
     if (w.count > 0) { D3 p = ray_at(ray, WR(w, 0)); WN(w, 0) = d3(p.x, p.y, p.z * P + 0.5 * Q); }
     if (w.count > 1) { D3 p = ray_at(ray, WR(w, 1)); WN(w, 1) = d3(p.x, p.y, p.z * P + 0.5 * Q); }
-    if (q.i0 == 1) {
+    if (nclip == 1) {
         clip_plane(ray, d3(0.0, 0.0, 1.0), w, 1, 1.0);
         clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
     }
-    if (q.i0 == -1) { a = -a; b = -b; c = -c; }
+    if (nclip == -1) { a = -a; b = -b; c = -c; }
     w.inside_inf = (a < 0.0) ? 1 : 0;
-    hit_list2(w, A, tag, prim, q.leaf_affine, ch);
 }
-
-__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)   /* Solids.cpp:769-781 */
+RT_DEV void poly_roots(const double *pl, const int nsides, const DRay &ray, Work &w)   /* Solids.cpp:769-781 */
 {
-    Work w;
     work_init(w);
-    const double *pl = planes + 3 * (size_t)p.plane0;
     int n = clip_plane(ray, d3(pl[0], pl[1], pl[2]), w, 0, 1.0);
-    for (int i = 1; n && i < p.i0; i++)
+    for (int i = 1; n && i < nsides; i++)
         n = clip_plane(ray, d3(pl[3 * i], pl[3 * i + 1], pl[3 * i + 2]), w, 1, 1.0);
-    hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
-
-__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)        /* Solids.cpp:859-869 */
+RT_DEV void slab_roots(const DRay &ray, Work &w)        /* Solids.cpp:859-869 */
 {
-    Work w;
     work_init(w);
     int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
     if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
+}
+__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+{
+    Work w;
+    quadric_roots(q.p[0], q.p[1], q.p[2], q.i0, ray, w);
+    hit_list2(w, A, tag, prim, q.leaf_affine, ch);
+}
+__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+{
+    Work w;
+    poly_roots(planes + 3 * (size_t)p.plane0, p.i0, ray, w);
+    hit_list2(w, A, tag, prim, p.leaf_affine, ch);
+}
+__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+{
+    Work w;
+    slab_roots(ray, w);
     hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
 
@@ -1114,7 +1160,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             /* CH_LDS: every chain record of the scene is staged in LDS (decided per launch, so that the loads below
                are LDS loads and not generic ones) */
             const RtChain &ch = CH_LDS ? L.chains[in.a] : S.chains[in.a];
-            if (ch.test_box && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b & 1) goto region_ret; break; }
+            if ((ch.test_box & RT_CHAIN_TEST_BOX) && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b & 1) goto region_ret; break; }
             DRay r = cur;
             if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
                 DRay nr;
@@ -1599,12 +1645,14 @@ __device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
 }
 
 /* TransformNormals, Shade.cpp:264-284.  LITE: a hit with queued texture call-outs sets bail instead. */
+/* own_minv (LITE callers that hold the hit's chain record, RT_CHAIN_OWN_NORMAL): the whole transform is that one matrix */
 template <bool LITE>
-__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail)
+__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail, const double *own_minv = 0)
 {
     h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat; h.has_color = 0; h.luster_ov = -1;
     if constexpr (LITE) {
         if (hr.ntex) { bail = true; return; }
+        if (own_minv) { h.n = covec_mat(h.n, own_minv); return; }
         for (int pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) h.n = covec_mat(h.n, S.affines[pa].minv);
         return;
     }

@@ -143,6 +143,8 @@ typedef struct RtBvhNode {
    order.  The record is self-contained (208 bytes: the affine, the primitive's parameters, what the wrappers do to
    a hit), so that one ray needs one record, and the first records of a scene are staged in LDS. */
 #define RT_CHAIN_WRAPS   6
+#define RT_CHAIN_TEST_BOX   1
+#define RT_CHAIN_OWN_NORMAL 2
 typedef struct RtChain {
     double  minv[9], tr[3];     /* the affine (n_affine == 1): AffineSolid after Optimize(), Solids.cpp:957-983 */
     double  p[3];               /* quadric P,Q,R ; torus: minor radius in p[0] */
@@ -151,7 +153,9 @@ typedef struct RtChain {
     int32_t leaf_affine;        /* affine the hits record (s_paLastHitAffine, Solids.cpp:213), -1 none */
     int32_t n_affine;           /* 0 or 1 */
     int32_t box;                /* the chain's conservative world box, -1 = unbounded */
-    int32_t test_box;           /* 0 when the caller (a region's BVH leaf) has already tested that box */
+    int32_t test_box;           /* bit 0: test the box (0 when the caller, a region's BVH leaf, has already tested it); bit 1 (RT_CHAIN_OWN_NORMAL): the
+                                   late normal transform of this chain's hits (Shade.cpp:271-279) is this record's own minv alone -- leaf_affine is the
+                                   chain's affine and has no parent link -- so a kernel that holds the record needs no affine table */
     int32_t n_wrap;
     int32_t wrap_dense;         /* bit w: wrapper w is a material of density > 0 */
     int32_t wrap[RT_CHAIN_WRAPS];       /* innermost first; >= 0: material index, < 0: ~surface index */
@@ -231,4 +235,5 @@ typedef struct RtDevScene {
     const RtBox      *region_child_boxes;   /* parallel to region_child_pc */
     const int32_t    *root_alt_pc;          /* root_cull == 1: per child of the root region, pc of "that chain for the root consumer; OP_END" behind the program, -1 = the child is not a bare chain */
     int32_t           n_root_alt, root_child_pc0;
+    const int32_t    *root_fast;            /* root_cull == 1: per child of the root region, the chain k_fast may run for a primary ray that can touch this child alone, -1 = not eligible; null = no fast path */
 } RtDevScene;

@@ -563,11 +563,11 @@ struct Flattener {
         if (with_bounds) {
             Box b = to_world(local_bound(i));
             if (b.empty && !no_root_bound) return true;         /* statically empty: nothing to emit */
-            if (!b.empty && b.finite()) { ch.box = add_box(b, true); ch.test_box = no_root_bound ? 0 : 1; if (ch.test_box) o.culled_subtrees++; }
+            if (!b.empty && b.finite()) { ch.box = add_box(b, true); ch.test_box = no_root_bound ? 0 : RT_CHAIN_TEST_BOX; if (ch.test_box) o.culled_subtrees++; }
         }
         ch.leaf_affine = -1;
         for (int k = 0; k < RT_CHAIN_WRAPS; k++) ch.wrap_tex[k] = -1;
-        int wraps[RT_CHAIN_WRAPS], wtex[RT_CHAIN_WRAPS], wdense[RT_CHAIN_WRAPS], tex_added = 0;
+        int wraps[RT_CHAIN_WRAPS], wtex[RT_CHAIN_WRAPS], wdense[RT_CHAIN_WRAPS], tex_added = 0, own_affine = -1;
         for (size_t k = 0; k < path.size(); k++) {
             int j = path[k];
             const RtNode &n = N(j);
@@ -584,6 +584,7 @@ struct Flattener {
                 Fwd f; memcpy(f.m, p, sizeof f.m); memcpy(f.t, p + 18, sizeof f.t);
                 affine_stack.push_back(ai); fwd_stack.push_back(f);
                 last_affine = ai;
+                own_affine = ai;
                 memcpy(ch.minv, a.minv, sizeof ch.minv); memcpy(ch.tr, a.tr, sizeof ch.tr);
                 ch.n_affine = 1;
             } else if (n.type == RT_NODE_MATERIAL) {
@@ -617,6 +618,9 @@ struct Flattener {
             ch.p[0] = pr.p[0]; ch.p[1] = pr.p[1]; ch.p[2] = pr.p[2];
             ch.i0 = pr.i0; ch.plane0 = pr.plane0; ch.leaf_affine = pr.leaf_affine;
         }
+        /* the hits' late normal transform walks leaf_affine's parent links (Shade.cpp:271-279): when that is this chain's own
+           affine and it has no parent, the record's minv is the whole transform */
+        if (own_affine >= 0 && ch.leaf_affine == own_affine && o.affines[own_affine].link < 0) ch.test_box |= RT_CHAIN_OWN_NORMAL;
         for (int k = 0; k < ch.n_wrap; k++) {                   /* innermost first */
             int src = ch.n_wrap - 1 - k;
             ch.wrap[k] = wraps[src]; ch.wrap_tex[k] = wtex[src];

@@ -380,19 +380,28 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleG
    workgroup run times). */
 #define RT_GEN_ITERS 6
 #define RT_GEN_SPAN  (RT_GEN_ITERS * 256)
+/* Survivors go one of two ways.  FAST: the sample's tile lists the children of the root region its rays can touch, the
+   (approximate, conservative) ray touches the box of exactly ONE of them, and that child is a bare chain of a two-root
+   primitive without rare features (RtDevScene.root_fast): the hit list of such a ray is that chain's list alone, at most
+   three hits, and k_fast handles it from (sample, chain) without a frame.  Everything else becomes a root frame for
+   k_visual as before.  Both queues are appended in sample order with one atomic per workgroup each. */
 __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir,
                                                        const double *rays_aux, float *out_rgb, float *out_spec)
 {
     const RtDevScene &S = Sv;
-    __shared__ int wave_count[RT_GEN_ITERS][4], wave_base[RT_GEN_ITERS][4], block_base;
+    __shared__ int wave_count[2][RT_GEN_ITERS][4], wave_base[2][RT_GEN_ITERS][4], block_base[2];
     const SceneLds lds = scene_lds_load(S, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = blockIdx.x * RT_GEN_SPAN;
-    unsigned keep_bits = 0;
-    unsigned long long prefix = 0;          /* 7 bits per iteration: survivors before this lane in its wave */
+    const bool fast_on = S.root_fast && g.tile_cand && !rays_org;
+    unsigned keep_bits = 0, fast_bits = 0;
+    unsigned long long prefix = 0, prefix_f = 0;    /* 7 bits per iteration: survivors of that kind before this lane in its wave */
+    int fast_chain[RT_GEN_ITERS];
+#pragma unroll
     for (int it = 0; it < RT_GEN_ITERS; it++) {
         int k = k0 + it * 256 + threadIdx.x;
-        bool keep = false;
+        bool keep = false, fast = false;
+        fast_chain[it] = -1;
         if (k < n) {
             k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
@@ -406,29 +415,45 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
                     const CullRay cr = cull_ray(r, RT_INFINITY);
                     const RtBox *cb = S.region_child_boxes + S.regions[S.root_cull_arg].child_pc0;
                     const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
-                    for (int q = 0; q < tm && !keep; q++) keep = cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr);
+                    if (fast_on) {
+                        int nh = 0, c1 = 0;
+                        for (int q = 0; q < tm && nh < 2; q++) if (cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr)) { nh++; c1 = tl[q]; }
+                        keep = nh > 0;
+                        if (nh == 1) { const int ch = S.root_fast[c1]; if (ch >= 0) { fast = true; keep = false; fast_chain[it] = ch; } }
+                    } else
+                        for (int q = 0; q < tm && !keep; q++) keep = cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr);
                 } else
                     keep = scene_may_hit(S, lds, r, RT_INFINITY);
             }
-            if (!keep && !(masked && g.mask_skips_rgb)) {
+            if (!keep && !fast && !(masked && g.mask_skips_rgb)) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
                 if (out_spec) for (int i = 0; i < RT_NSPEC; i++) out_spec[(size_t)k * RT_NSPEC + i] = 0.0f;
             }
         }
-        unsigned long long b = __ballot(keep);
+        const unsigned long long b = __ballot(keep), bf = __ballot(fast), below = (1ull << lane) - 1ull;
         if (keep) keep_bits |= 1u << it;
-        prefix |= (unsigned long long)__popcll(b & ((1ull << lane) - 1ull)) << (7 * it);
-        if (lane == 0) wave_count[it][wave] = __popcll(b);
+        if (fast) fast_bits |= 1u << it;
+        prefix |= (unsigned long long)__popcll(b & below) << (7 * it);
+        prefix_f |= (unsigned long long)__popcll(bf & below) << (7 * it);
+        if (lane == 0) { wave_count[0][it][wave] = __popcll(b); wave_count[1][it][wave] = __popcll(bf); }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 2) {
+        const int q = threadIdx.x;
         int total = 0;
         for (int it = 0; it < RT_GEN_ITERS; it++)
-            for (int w = 0; w < 4; w++) { wave_base[it][w] = total; total += wave_count[it][w]; }
-        block_base = total > 0 ? atomicAdd(&P.counters[CTR_FRAMES], total) : 0;
+            for (int w = 0; w < 4; w++) { wave_base[q][it][w] = total; total += wave_count[q][it][w]; }
+        block_base[q] = total > 0 ? atomicAdd(&P.counters[q ? CTR_FAST : CTR_FRAMES], total) : 0;
     }
     __syncthreads();
+#pragma unroll
     for (int it = 0; it < RT_GEN_ITERS; it++) {
+        if (fast_bits & (1u << it)) {
+            const int k = trace_order(g, first, k0 + it * 256 + threadIdx.x);
+            const int e = block_base[1] + wave_base[1][it][wave] + (int)((prefix_f >> (7 * it)) & 127u);
+            nt_store(&P.fast_q[e], k);
+            nt_store(&P.fast_q[(size_t)P.ncap + e], fast_chain[it]);
+        }
         if (!(keep_bits & (1u << it))) continue;
         const int k = trace_order(g, first, k0 + it * 256 + threadIdx.x);
         double aux[6];
@@ -439,7 +464,29 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
             const int64_t tile = (first + k) / RT_BLUE_N;
             if (g.tile_mask[tile] == 1) { const int c = g.tile_cand[(size_t)tile * RT_TILE_CAND]; if (c < 4095) hint = c + 1; }
         }
-        root_frame(S, P, block_base + wave_base[it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux, hint);
+        root_frame(S, P, block_base[0] + wave_base[0][it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux, hint);
+    }
+}
+
+/* first kernel of a pass: every counter to zero except the overflow line (kept for the whole render call), the frame
+   count to the number of root frames k_generate makes (0 when k_generate_cull counts them itself) */
+__global__ void k_pass_begin(int *counters, int frames0)
+{
+    for (int i = threadIdx.x; i < CTR_COUNT; i += blockDim.x)
+        if (i < CTR_OVERFLOW || i >= CTR_OVERFLOW + CTR_LINE) counters[i] = (i == CTR_FRAMES) ? frames0 : 0;
+}
+/* between the tracing kernels and the shading of a level: freeze the level's frame and shadow-ray counts where the next
+   kernels of the stream read them (k_shade appends the next level's frames to CTR_FRAMES while it runs) */
+__global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
+{
+    if (threadIdx.x == 0) {
+        const int nf = P.counters[CTR_FRAMES], ns = P.counters[CTR_SHADOW];
+        P.counters[CTR_SNAP] = nf < P.fcap ? nf : P.fcap;
+        P.counters[CTR_SNAP + 1] = ns < P.scap ? ns : P.scap;
+        if (level0) {           /* measurement: how the call's primary rays were traced (the line outlives the pass) */
+            P.counters[CTR_OVERFLOW + 2] += P.counters[CTR_FAST];
+            P.counters[CTR_OVERFLOW + 3] += gen_frames < 0 ? P.counters[CTR_SNAP + 2] : gen_frames;
+        }
     }
 }
 
@@ -473,6 +520,186 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
  * metal is put on the slow list instead and redone by the FULL instantiation (launched over that list). */
 /* MODE: what the workgroup stages in LDS besides the top of the BVH -- 0 nothing, 1 the chain records, 2 the chain records
    and the small scene tables (scene_lds_load); chosen per scene at upload, compiled in so that the loads are LDS loads */
+/* What the walk of one visual ray through its hit list leaves behind (Shade.cpp:424-516): whether it stopped at a
+   boundary, the radiance and transmittance gathered on the way, and which lights need a shadow ray.  The boundary's
+   geometry goes to a SINK the moment it is known: k_visual's sink stores it as the frame record for k_shade (the values
+   die at once: the interpreter kernels have no registers to keep them), k_fast's keeps it in registers and finishes the
+   sample from it where nothing else is needed. */
+struct Walk {
+    int      flags;             /* FR_BOUNDARY | FR_PERTURBED | FR_FINAL | FR_FIN */
+    unsigned mask;              /* lights that get a shadow ray (Shade.cpp:477-481) */
+    int      n_shadow;
+    bool     bail;              /* LITE: a rare feature on the way -- redo the ray in the FULL kernel */
+    bool     tr_one;
+    int      r_state;           /* 0: R is zero, 1: R is the boundary's ambient term alone, 2: anything else */
+    D3       P;                 /* the boundary point (origin of the shadow rays) */
+    Spec     R, tr;
+};
+struct FrameSink {              /* the frame record of frame f; `flags` collects what k_shade can tell from a flag instead of a load */
+    const RtPipe &P; int f; int flags;
+    RT_DEV void boundary(const D3 &Ppt, const D3 &cvN, const D3 &vE, const D3 &hn, double fNE, double F, double fNT, double eta,
+                         int rough, int luster, int mat, const Spec &color, bool color_is_mat)
+    {
+        d3_store(P.f_geo, P.fcap, GEO_P, f, Ppt);
+        d3_store(P.f_geo, P.fcap, GEO_N, f, cvN);
+        d3_store(P.f_geo, P.fcap, GEO_E, f, vE);
+        d3_store(P.f_geo, P.fcap, GEO_HN, f, hn);
+        P.f_geo[(size_t)GEO_FNE * P.fcap + f] = fNE;
+        P.f_geo[(size_t)GEO_F * P.fcap + f] = F;
+        P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
+        P.f_geo[(size_t)GEO_ETA * P.fcap + f] = eta;
+        P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
+        P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = luster | (mat << 8);
+        if (color_is_mat) flags |= FR_COLOR_MAT; else spec_store(P.f_color, P.fcap, f, color);
+    }
+    RT_DEV void fin(const Spec &v) { spec_store(P.f_fin, P.fcap, f, v); }
+};
+struct RegSink {                /* the same values, kept */
+    D3 N, E, HN; double fNE, F, fNT, eta; int rough, luster, mat; Spec color; bool color_is_mat;
+    RT_DEV void boundary(const D3 &, const D3 &cvN, const D3 &vE, const D3 &hn, double fNE_, double F_, double fNT_, double eta_,
+                         int rough_, int luster_, int mat_, const Spec &color_, bool color_is_mat_)
+    {
+        N = cvN; E = vE; HN = hn; fNE = fNE_; F = F_; fNT = fNT_; eta = eta_; rough = rough_; luster = luster_; mat = mat_; color = color_; color_is_mat = color_is_mat_;
+    }
+    RT_DEV void fin(const Spec &) {}
+};
+struct ArenaHits {              /* a hit list in the interpreter's arena */
+    const Arena &A; int start;
+    RT_DEV const HitRec &get(int i) const { return A.h[start + i]; }
+    RT_DEV const double *own_minv() const { return 0; }
+};
+
+template <bool LITE, class Hits, class Sink>
+RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux, const Hits &H, const int count, Walk &B, Sink &K)
+{
+    B.flags = 0; B.mask = 0; B.n_shadow = 0; B.bail = false; B.tr_one = true; B.r_state = 0;
+    B.P = d3(0, 0, 0);
+    /* Shade.cpp:424-432: regularise into (0, t, ...) */
+    int i = 0, pm = 0;
+    if (count > 0 && !(H.get(0).t > 0.0)) { pm = H.get(0).mat; i = 1; }
+    double t = 0.0;
+    Spec tr = spec_const(1.0f), R = spec_const(0.0f);
+    /* Q13: colour / luster a solid texture gave the material the walk is inside of (FULL kernel only: LITE hands
+       textured hits over) */
+    int pm_luster_ov = -1, pm_has_color = 0;
+    Spec pm_color = spec_const(0.0f);
+    bool bail = false;
+    for (; i < count && !bail; i++) {
+        ShadeHit h;
+        transform_normals<LITE>(S, ray, H.get(i), h, aux, bail, H.own_minv());
+        if (bail) break;
+        const RtMaterialDev &mp = S.mats[pm];
+        int mp_luster = mp.luster;
+        const float *mp_colorp = mp.color;
+        if constexpr (!LITE) { if (pm_luster_ov >= 0) mp_luster = pm_luster_ov; if (pm_has_color) mp_colorp = pm_color.v; }
+        if (mp_luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
+            R = spec_load(mp_colorp);
+            B.r_state = 2;
+            B.flags |= FR_FINAL;
+            break;
+        }
+        if (mp.prop) {
+            if constexpr (LITE) { bail = true; break; }
+            else {
+                Spec ptr, pst;
+                propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
+                tr = tr * ptr;
+                R = R + pst;
+                B.r_state = 2; B.tr_one = false;
+            }
+        }
+        const RtMaterialDev &mh = S.mats[h.mat];
+        int mh_luster = mh.luster;
+        if constexpr (!LITE) if (h.luster_ov >= 0) mh_luster = h.luster_ov;
+        if ((mp.refr != mh.refr) || (mh_luster != RT_MAT_TRANSPARENT)) {
+            D3 vE, cvN;
+            double fNE, F = 0.0, fNT = 0.0;
+            consistent_normal(ray, h, vE, cvN, fNE);
+            Spec color = spec_load(mh.color);
+            bool color_is_mat = true;
+            if constexpr (!LITE) if (h.has_color) { color = h.color; color_is_mat = false; }
+            if (spectral_metal(mh_luster)) {                /* Q3 */
+                if constexpr (LITE) { bail = true; break; }
+                else {
+                    color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC + RT_NSPEC);
+                    F = 1.0;
+                    color_is_mat = false;
+                }
+            } else
+                fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
+            int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
+            if (S.has_ambient && rough != RT_SURF_POLISHED) {
+                Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
+                R = R + color * E;
+                B.r_state = (B.r_state == 0 && color_is_mat) ? 1 : 2;
+            }
+            const D3 Ppt = ray_at(ray, h.t);
+            /* which lights get a shadow ray (Shade.cpp:477-481) */
+            for (int li = 0; li < S.n_lights; li++) {
+                const RtLightDev &l = S.lights[li];
+                D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+                if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+                D3 dir = lo - Ppt;
+                if (dot(cvN, dir) <= 0.0 && mh_luster != RT_MAT_TRANSPARENT) continue;
+                if (l.no_shadow) continue;
+                B.mask |= 1u << li;
+                B.n_shadow++;
+            }
+            B.flags |= FR_BOUNDARY;
+            if (h.perturbed) B.flags |= FR_PERTURBED;
+            B.P = Ppt;
+            K.boundary(Ppt, cvN, vE, h.n, fNE, F, fNT, mp.refr / mh.refr, rough, mh_luster, h.mat, color, color_is_mat);
+            t = h.t;
+            pm = h.mat;
+            if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
+            break;
+        } else {
+            t = h.t;
+            pm = h.mat;
+            if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
+        }
+    }
+    if (!bail && !(B.flags & FR_FINAL) && S.mats[pm].prop) {  /* Shade.cpp:512-516 */
+        if constexpr (LITE) bail = true;
+        else {
+            Spec ptr, pst;
+            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
+            K.fin(tr * pst);
+            B.flags |= FR_FIN;
+        }
+    }
+    B.bail = bail;
+    B.R = R; B.tr = tr;
+}
+
+/* what is left of a frame record after the walk: radiance and transmittance, as flags where a flag says it all (bytes
+   not written are the cheapest); returns the frame's flags word */
+template <bool LITE>
+RT_DEV int frame_finish(const RtPipe &P, const int f, const Walk &B, int flags)
+{
+    flags |= B.flags;
+    if (B.r_state == 0) flags |= FR_R_ZERO; else if (B.r_state == 1) flags |= FR_R_AMBIENT; else spec_store(P.f_R, P.fcap, f, B.R);
+    if (LITE || B.tr_one) flags |= FR_TR_ONE; else spec_store(P.f_tr, P.fcap, f, B.tr);
+    return flags;
+}
+/* the shadow rays of a stored frame: slots [base, base + n_shadow) of the queue, in light order */
+RT_DEV void shadow_append(const RtDevScene &S, const RtPipe &P, const Walk &B, const int base, const int root, const double *aux)
+{
+    int k = 0;
+    for (int li = 0; li < S.n_lights; li++) {
+        if (!(B.mask & (1u << li))) continue;
+        int s = base + k++;
+        if (s >= P.scap) continue;          /* overflow is reported by the host from the counter */
+        const RtLightDev &l = S.lights[li];
+        D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+        if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+        d3_store(P.s_ray, P.scap, 0, s, B.P);
+        d3_store(P.s_ray, P.scap, 3, s, lo - B.P);
+        P.s_light[s] = li;
+        P.s_root[s] = root;
+    }
+}
+
 template <bool LITE, int MODE, bool TILES = false>
 __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
@@ -482,7 +709,14 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     const RtDevScene &S = SL;
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
-    /* FULL: over the slow list the LITE launch left, or (f1 > f0: a small level, no LITE launch before it) over the frames themselves */
+    /* LITE, f1 < 0: the root frames k_generate_cull made -- their number is on the device (no kernel of the stream changes it
+       while this one runs).  FULL: over the slow list the LITE launch left, or (f1 > f0: a small level, no LITE launch
+       before it) over the frames themselves */
+    if (LITE && f1 < 0) {
+        f1 = P.counters[CTR_FRAMES];
+        if (f1 > P.fcap) f1 = P.fcap;
+        if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[CTR_SNAP + 2] = f1;     /* k_fast appends behind them: remembered for the statistics */
+    }
     const bool direct = LITE || f1 > f0;
     const int n = direct ? (f1 - f0) : P.counters[CTR_SLOW_V];
     int *const work = &P.counters[LITE ? CTR_WORK_V : CTR_WORK_VS];
@@ -506,19 +740,17 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     long long prof_t0 = clock64();
     int prof_v[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
-    int n_shadow = 0;
-    unsigned mask = 0;
-    D3 Ppt = d3(0, 0, 0);
+    Walk B;
+    B.n_shadow = 0; B.mask = 0; B.bail = false;
     double aux[6];
-    int flags = 0;
-    bool bail = false;
+    int flags = 0, root = 0;
     if (live) {
         const int flags_raw = P.f_flags[f];
         flags = flags_raw & FR_KEEP_MASK;
         DRay ray;
         ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
         ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
-        int root = P.f_root[f];
+        root = P.f_root[f];
         aux_load<LITE>(S, P, root, aux);
         Arena A;
         int start;
@@ -535,129 +767,27 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         }
         int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
-        bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
         for (int q = 1; q < 8; q++) prof_v[q] = A.prof[q];
         prof_v[8] = (int)(clock64() - prof_t0);
 #endif
-        /* Shade.cpp:424-432: regularise into (0, t, ...) */
-        int i = 0, pm = 0;
-        if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
-        double t = 0.0;
-        Spec tr = spec_const(1.0f), R = spec_const(0.0f);
-        int r_state = 0;                /* 0: R is zero, 1: R is the boundary's ambient term alone, 2: anything else */
-        bool tr_one = true;
-        /* Q13: colour / luster a solid texture gave the material the walk is inside of (FULL kernel only: LITE hands
-           textured hits over) */
-        int pm_luster_ov = -1, pm_has_color = 0;
-        Spec pm_color = spec_const(0.0f);
-        for (; i < count && !bail; i++) {
-            ShadeHit h;
-            transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
-            if (bail) break;
-            const RtMaterialDev &mp = S.mats[pm];
-            int mp_luster = mp.luster;
-            const float *mp_colorp = mp.color;
-            if constexpr (!LITE) { if (pm_luster_ov >= 0) mp_luster = pm_luster_ov; if (pm_has_color) mp_colorp = pm_color.v; }
-            if (mp_luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
-                R = spec_load(mp_colorp);
-                r_state = 2;
-                flags |= FR_FINAL;
-                break;
-            }
-            if (mp.prop) {
-                if constexpr (LITE) { bail = true; break; }
-                else {
-                    Spec ptr, pst;
-                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
-                    tr = tr * ptr;
-                    R = R + pst;
-                    r_state = 2; tr_one = false;
-                }
-            }
-            const RtMaterialDev &mh = S.mats[h.mat];
-            int mh_luster = mh.luster;
-            if constexpr (!LITE) if (h.luster_ov >= 0) mh_luster = h.luster_ov;
-            if ((mp.refr != mh.refr) || (mh_luster != RT_MAT_TRANSPARENT)) {
-                D3 vE, cvN;
-                double fNE, F = 0.0, fNT = 0.0;
-                consistent_normal(ray, h, vE, cvN, fNE);
-                Spec color = spec_load(mh.color);
-                bool color_is_mat = true;
-                if constexpr (!LITE) if (h.has_color) { color = h.color; color_is_mat = false; }
-                if (spectral_metal(mh_luster)) {                /* Q3 */
-                    if constexpr (LITE) { bail = true; break; }
-                    else {
-                        color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC + RT_NSPEC);
-                        F = 1.0;
-                        color_is_mat = false;
-                    }
-                } else
-                    fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
-                int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
-                if (S.has_ambient && rough != RT_SURF_POLISHED) {
-                    Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
-                    R = R + color * E;
-                    r_state = (r_state == 0 && color_is_mat) ? 1 : 2;
-                }
-                Ppt = ray_at(ray, h.t);
-                /* which lights get a shadow ray (Shade.cpp:477-481) */
-                for (int li = 0; li < S.n_lights; li++) {
-                    const RtLightDev &l = S.lights[li];
-                    D3 lo = d3(l.org[0], l.org[1], l.org[2]);
-                    if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
-                    D3 dir = lo - Ppt;
-                    if (dot(cvN, dir) <= 0.0 && mh_luster != RT_MAT_TRANSPARENT) continue;
-                    if (l.no_shadow) continue;
-                    mask |= 1u << li;
-                    n_shadow++;
-                }
-                flags |= FR_BOUNDARY;
-                if (h.perturbed) flags |= FR_PERTURBED;
-                d3_store(P.f_geo, P.fcap, GEO_P, f, Ppt);
-                d3_store(P.f_geo, P.fcap, GEO_N, f, cvN);
-                d3_store(P.f_geo, P.fcap, GEO_E, f, vE);
-                d3_store(P.f_geo, P.fcap, GEO_HN, f, h.n);
-                P.f_geo[(size_t)GEO_FNE * P.fcap + f] = fNE;
-                P.f_geo[(size_t)GEO_F * P.fcap + f] = F;
-                P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
-                P.f_geo[(size_t)GEO_ETA * P.fcap + f] = mp.refr / mh.refr;
-                P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
-                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh_luster | ((int)h.mat << 8);
-                if (color_is_mat) flags |= FR_COLOR_MAT; else spec_store(P.f_color, P.fcap, f, color);
-                t = h.t;
-                pm = h.mat;
-                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
-                break;
-            } else {
-                t = h.t;
-                pm = h.mat;
-                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
-            }
-        }
-        if (!bail && !(flags & FR_FINAL) && S.mats[pm].prop) {  /* Shade.cpp:512-516 */
-            if constexpr (LITE) bail = true;
-            else {
-                Spec ptr, pst;
-                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
-                spec_store(P.f_fin, P.fcap, f, tr * pst);
-                flags |= FR_FIN;
-            }
-        }
-        if (!bail) {
-            if (r_state == 0) flags |= FR_R_ZERO; else if (r_state == 1) flags |= FR_R_AMBIENT; else spec_store(P.f_R, P.fcap, f, R);
-            if (tr_one) flags |= FR_TR_ONE; else spec_store(P.f_tr, P.fcap, f, tr);
+        if (A.bail) B.bail = true;
+        else {
+            const ArenaHits H = { A, start };
+            FrameSink K = { P, f, flags };
+            visual_walk<LITE>(S, ray, aux, H, count, B, K);
+            if (!B.bail) flags = frame_finish<LITE>(P, f, B, K.flags);
         }
     }
     /* append this lane's shadow rays to the queue and (LITE) the frame to the slow list: one atomic per wave for both */
     int base;
     if constexpr (LITE) {
-        if (bail) { n_shadow = 0; mask = 0; }
+        if (B.bail) { B.n_shadow = 0; B.mask = 0; }
         int slot;
-        wave_alloc2(n_shadow, bail ? 1 : 0, &P.counters[CTR_SHADOW], base, slot);
-        if (bail) P.slow_v[slot] = f;
+        wave_alloc2(B.n_shadow, B.bail ? 1 : 0, &P.counters[CTR_SHADOW], base, slot);
+        if (B.bail) P.slow_v[slot] = f;
     } else
-        base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
+        base = wave_alloc(B.n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
     for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 1024 cycles (int counters: 16 overflowed on long frames) */
@@ -666,25 +796,167 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 10);
     }
 #endif
-    if (!live || bail) continue;
+    if (!live || B.bail) continue;
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
-    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
+    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)B.mask;
     P.f_flags[f] = flags;
-    if (n_shadow) {
-        int k = 0;
-        for (int li = 0; li < S.n_lights; li++) {
+    if (B.n_shadow) shadow_append(S, P, B, base, root, aux);
+  }
+}
+
+/* ------------------------------------------------------------------ k_fast (no counterpart in the reference)
+ * Primary rays of the fast queue: VisualRay (Shade.cpp:401-520) for a ray whose hit list is ONE chain's -- affine,
+ * two-root primitive, Material / Surface wrappers -- without the interpreter and without a hit arena: the (at most
+ * three) hits stay in registers.  The ray is recomputed from the sample index (same arithmetic as the generator's
+ * exact ray).  A sample that needs neither a shadow ray nor a reflection / refraction child is finished here: the light
+ * loop of Shade.cpp:477-489 for its (nNoShadow) lights and the conversion to RGB, so it never becomes a frame.  Otherwise the lane
+ * allocates a frame, stores the record k_visual would have stored and queues the shadow rays; k_shade takes it from
+ * there.  The host only routes chains here that cannot need the FULL kernels (no torus / mesh, texture call-out,
+ * propagator or spectral metal anywhere in the chain), so `bail` is an internal error, reported as an overflow. */
+#define OVF_FAST_BAIL 64
+template <class FetchE>
+RT_DEV Spec light_loop(const RtDevScene &S, const D3 &Ppt, const D3 &cvN, const D3 &vE, const D3 &hn, const double F, const int rough, const int luster,
+                       const Spec &color, Spec R, const double uL, const double vL_, const unsigned mask, const FetchE &fetch)
+{
+    for (int li = 0; li < S.n_lights; li++) {
+        const RtLightDev &l = S.lights[li];
+        D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+        if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * uL + d3(l.vB[0], l.vB[1], l.vB[2]) * vL_;
+        D3 dir = lo - Ppt;
+        if (dot(cvN, dir) <= 0.0 && luster != RT_MAT_TRANSPARENT) continue;
+        D3 vL = normalize(dir);
+        double fNL = dot(cvN, vL);
+        Spec Eraw;
+        if (l.no_shadow) Eraw = spec_div(spec_load(l.flux), 4.0 * RT_PI * dot(dir, dir));      /* Shade.cpp:315-318 */
+        else {
+            /* the shadow ray queued for this light: its slot follows from the mask stored with the frame, not from this
+               loop's own count -- a light that was not queued (it cannot happen while the two predicates are the same
+               code) contributes nothing instead of shifting the others' slots */
             if (!(mask & (1u << li))) continue;
-            int s = base + k++;
-            if (s >= P.scap) continue;          /* overflow is reported by the host from the counter */
-            const RtLightDev &l = S.lights[li];
-            D3 lo = d3(l.org[0], l.org[1], l.org[2]);
-            if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
-            d3_store(P.s_ray, P.scap, 0, s, Ppt);
-            d3_store(P.s_ray, P.scap, 3, s, lo - Ppt);
-            P.s_light[s] = li;
-            P.s_root[s] = P.f_root[f];
+            if (!fetch(__popc(mask & ((1u << li) - 1u)), Eraw)) continue;
+        }
+        Spec E = Eraw * fNL;
+        if (spec_is_black(E)) continue;
+        Spec refl = brdf(rough, luster, color, hn, vL, vE, cvN, F);
+        R = R + refl * E;
+    }
+    return R;
+}
+RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec);
+
+/* 512 threads = two waves per SIMD and 256 registers: measured on S0 4K / 64 spp, 512 / 768 / 1024 threads = 0.54 / 0.59 / 0.69 ms
+   per launch of 5.4 M rays -- what the narrower builds spill (480 B and 700 B per lane) costs more than the waves they add */
+#ifndef RT_FAST_THREADS
+#define RT_FAST_THREADS 512
+#endif
+/* MODE 1: the workgroup stages everything a fast ray looks up per lane -- chain records, the blue-noise tile and its two
+   permutations, materials, surfaces -- in LDS (rt_scene_upload checks that it fits: S0 needs 117 KB); MODE 0: nothing is
+   staged.  The loads below then are LDS instructions: the pointers are derived from the LDS base inside this function. */
+RT_HD size_t fast_lds_bytes(int n_chains, int n_mats, int n_surfs)
+{
+    return (size_t)n_chains * sizeof(RtChain) + (size_t)2 * RT_BLUE_N * sizeof(double) + (size_t)2 * RT_BLUE_N * sizeof(int32_t) +
+           (size_t)n_mats * sizeof(RtMaterialDev) + (size_t)n_surfs * sizeof(RtSurfaceDev) + 64;
+}
+template <int MODE>
+__global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k_fast(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, float *out_rgb, float *out_spec)
+{
+    RtDevScene SL = Sv;
+    const RtChain *chains = Sv.chains;
+    if constexpr (MODE == 1) {
+        extern __shared__ double rt_dyn_lds[];
+        double *cur = rt_dyn_lds;
+        chains = lds_stage(cur, Sv.chains, Sv.n_chains);
+        SL.blue = lds_stage(cur, Sv.blue, 2 * RT_BLUE_N);
+        SL.qi2 = lds_stage(cur, Sv.qi2, RT_BLUE_N);
+        SL.qi3 = lds_stage(cur, Sv.qi3, RT_BLUE_N);
+        SL.mats = lds_stage(cur, Sv.mats, Sv.n_mats);
+        SL.surfs = lds_stage(cur, Sv.surfs, Sv.n_surfs);
+        __syncthreads();
+    }
+    const RtDevScene &S = SL;
+    int n = P.counters[CTR_FAST];
+    if (n > P.ncap) n = P.ncap;
+    int *const work = &P.counters[CTR_WORK_F];
+    const int wlane = threadIdx.x & 63;
+  int wnext = 0, wlimit = 0;
+  for (;;) {
+    if (wnext >= wlimit) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, RT_CLAIM);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        wnext = b; wlimit = b + RT_CLAIM < n ? b + RT_CLAIM : n;
+    }
+    const int e = wnext + wlane;
+    wnext += 64;
+    const bool live = e < n;
+    Walk B;
+    RegSink K;
+    B.n_shadow = 0; B.mask = 0; B.bail = false; B.flags = 0;
+    double aux[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };    /* only the light pair is ever read here (no aperture camera, no texture call-out on this path) */
+    int k = 0;
+    bool need_frame = false;
+    if (live) {
+        k = nt_load(&P.fast_q[e]);
+        const int ci = nt_load(&P.fast_q[(size_t)P.ncap + e]);
+        DRay ray;
+        {   /* FastBlueSamplingTile::Render, Sampling.cpp:498-517 + CastFunction, RayTracer2020.cpp:20-31: as sample_at / root_ray */
+            const int64_t sidx = first + k;
+            const uint32_t tile = (uint32_t)(sidx / RT_BLUE_N);
+            const int i = (int)(sidx - (int64_t)tile * RT_BLUE_N);
+            const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+            const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
+            const double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
+            const double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + vtx, vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + vty;
+            const double v0 = (vx + g.adjust_x) / g.size, v1 = (vy + g.adjust_y) / g.size;
+            if (S.aux_light) {
+                const int q2 = S.qi2[i % RT_BLUE_N];
+                aux[2] = 2.0 * S.blue[2 * q2] - 1.0;
+                aux[3] = 2.0 * S.blue[2 * q2 + 1] - 1.0;
+            }
+            ray = camera_emit(S.cam, v0, v1, 0.0, 0.0);
+        }
+        const RtChain &ch = chains[ci];
+        DRay r = ray;
+        if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
+            DRay nr;
+            nr.dir = mat_vec(ch.minv, r.dir);
+            nr.org = mat_vec(ch.minv, r.org - d3(ch.tr[0], ch.tr[1], ch.tr[2]));
+            r = nr;
+        }
+        Work w;
+        if (ch.prim_op == OP_QUADRIC) quadric_roots(ch.p[0], ch.p[1], ch.p[2], ch.i0, r, w);
+        else if (ch.prim_op == OP_POLY) poly_roots(S.planes + 3 * (size_t)ch.plane0, ch.i0, r, w);
+        else slab_roots(r, w);
+        RegEmit H;
+        H.minv_own = (ch.test_box & RT_CHAIN_OWN_NORMAL) ? ch.minv : (const double *)0;
+        hit_list2_core(w, H, (uint16_t)ch.prim, ch.leaf_affine, &ch);
+        visual_walk<true>(S, ray, aux, H, H.L, B, K);
+        if (B.bail) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL); B.n_shadow = 0; B.mask = 0; }
+        else if ((B.flags & FR_BOUNDARY) && (B.n_shadow > 0 || K.rough == RT_SURF_POLISHED)) need_frame = true;
+        else {
+            Spec R = B.R;
+            if (B.flags & FR_BOUNDARY)
+                R = light_loop(S, B.P, K.N, K.E, K.HN, K.F, K.rough, K.luster, K.color, R, aux[2], aux[3], 0u, [](int, Spec &) { return false; });
+            sample_deliver(S, k, R, out_rgb, out_spec);
         }
     }
+    /* the lanes that could not finish become level-0 frames behind the generator's (k_visual has run by now) */
+    if (__ballot(need_frame) == 0ull) continue;
+    const int f = wave_alloc(need_frame ? 1 : 0, &P.counters[CTR_FRAMES]);
+    const int base = wave_alloc(need_frame ? B.n_shadow : 0, &P.counters[CTR_SHADOW]);
+    if (!need_frame || f >= P.fcap) continue;               /* a full pool is reported by the host from the counter */
+    aux[4] = aux[2]; aux[5] = aux[3];                       /* the micro-facet pair follows the light's permutation (Sampling.cpp:512-515) */
+    aux_store(S, P, k, aux);
+    P.f_parent[f] = -1;
+    P.f_root[f] = k;
+    FrameSink FS = { P, f, 0 };
+    if (B.flags & FR_BOUNDARY) FS.boundary(B.P, K.N, K.E, K.HN, K.fNE, K.F, K.fNT, K.eta, K.rough, K.luster, K.mat, K.color, K.color_is_mat);
+    const int flags = frame_finish<true>(P, f, B, FS.flags);
+    P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
+    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)B.mask;
+    P.f_flags[f] = flags;
+    if (B.n_shadow) shadow_append(S, P, B, base, k, aux);
   }
 }
 
@@ -697,6 +969,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     RtDevScene SL = Sv;
     const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
+    if (LITE && nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
     const bool direct = LITE || nrays > 0;      /* FULL: nrays == 0 = the slow list of the LITE launch before it */
     const int n = direct ? nrays : P.counters[CTR_SLOW_S];
     int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
@@ -798,12 +1071,16 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
 
 RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec);
 
-/* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501) */
-__global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+/* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501)
+ * Frames [f0, f1) of one level, grid-stride (the host launches a few workgroups per CU whatever the count); f1 < 0: the
+ * level's end is on the device (CTR_SNAP, written by k_level_snap behind the tracing kernels). */
+__global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
 {
-    int f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = f < f1;
     const RtDevScene &S = Sv;
+    if (f1 < 0) f1 = P.counters[CTR_SNAP];
+  for (int fb = f0 + blockIdx.x * 256; fb < f1; fb += gridDim.x * 256) {
+    const int f = fb + threadIdx.x;
+    const bool live = f < f1;
     int nchild = 0, flags = 0;
     bool want_refl = false, want_refr = false, have_R = false;
     Spec Rfin;
@@ -823,36 +1100,15 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
             int rough = P.f_ids[(size_t)IDS_ROUGH * P.fcap + f], luster = P.f_ids[(size_t)IDS_LUSTER * P.fcap + f];
             const int mat = luster >> 8;
             luster &= 0xFF;
-            int base = P.f_ids[(size_t)IDS_SHBASE * P.fcap + f];
-            unsigned mask = (unsigned)P.f_ids[(size_t)IDS_SHMASK * P.fcap + f];
+            const int base = P.f_ids[(size_t)IDS_SHBASE * P.fcap + f];
+            const unsigned mask = (unsigned)P.f_ids[(size_t)IDS_SHMASK * P.fcap + f];
             Spec color = (flags & FR_COLOR_MAT) ? spec_load(S.mats[mat].color) : spec_fetch(P.f_color, P.fcap, f), R;
             if (flags & FR_R_ZERO) R = spec_const(0.0f);
             else if (flags & FR_R_AMBIENT) { Spec E = spec_load(S.ambient) * RT_PI; R = spec_const(0.0f); R = R + color * E; }     /* as k_visual would have */
             else R = spec_fetch(P.f_R, P.fcap, f);
-            int k;
-            for (int li = 0; li < S.n_lights; li++) {
-                const RtLightDev &l = S.lights[li];
-                D3 lo = d3(l.org[0], l.org[1], l.org[2]);
-                if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * uL + d3(l.vB[0], l.vB[1], l.vB[2]) * vL_;
-                D3 dir = lo - Ppt;
-                if (dot(cvN, dir) <= 0.0 && luster != RT_MAT_TRANSPARENT) continue;
-                D3 vL = normalize(dir);
-                double fNL = dot(cvN, vL);
-                Spec Eraw;
-                if (l.no_shadow) Eraw = spec_div(spec_load(l.flux), 4.0 * RT_PI * dot(dir, dir));      /* Shade.cpp:315-318 */
-                else {
-                    /* the shadow ray k_visual queued for this light: its slot follows from the mask k_visual stored, not
-                       from this loop's own count -- a light k_visual did not queue (it cannot happen while the two
-                       predicates are the same code) contributes nothing instead of shifting the others' slots */
-                    if (!(mask & (1u << li))) continue;
-                    k = __popc(mask & ((1u << li) - 1u));
-                    Eraw = spec_fetch(P.s_E, P.scap, base + k);
-                }
-                Spec E = Eraw * fNL;
-                if (spec_is_black(E)) continue;
-                Spec refl = brdf(rough, luster, color, hn, vL, vE, cvN, F);
-                R = R + refl * E;
-            }
+            /* a slot beyond the queue: the pass overflowed, the host discards and splits it */
+            R = light_loop(S, Ppt, cvN, vE, hn, F, rough, luster, color, R, uL, vL_, mask,
+                           [&](int k, Spec &E) { if (base + k >= P.scap) return false; E = spec_fetch(P.s_E, P.scap, base + k); return true; });
             Rfin = R; have_R = true;
             if (rough == RT_SURF_POLISHED) {
                 int perturbed = (flags & FR_PERTURBED) ? 1 : 0;
@@ -885,7 +1141,7 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
         }
     }
     int base = wave_alloc(nchild, &P.counters[CTR_FRAMES]);
-    if (!live || nchild == 0) return;
+    if (!live || nchild == 0) continue;
     int c = base;
     for (int which = 0; which < 2; which++) {
         if (which == 0 ? !want_refl : !want_refr) continue;
@@ -897,19 +1153,13 @@ __global__ void __launch_bounds__(256) k_shade(const RtDevScene Sv, RtPipe P, in
         P.f_root[nf] = P.f_root[f];
         P.f_flags[nf] = FR_MAKE_DEPTH(depth + 1) | (which ? FR_SLOT2 : 0);
     }
+  }
 }
 
 /* ------------------------------------------------------------------ k_resolve */
-/* hand a frame's finished radiance to its parent (Shade.cpp:491-501) or, for a root, to the sample:
-   Spectrum::sRGB / vRGB (RadiometryColor.h:62-66, RadiometryColor.cpp:971-983) */
-RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec)
+/* a root's finished radiance to its sample: Spectrum::sRGB / vRGB (RadiometryColor.h:62-66, RadiometryColor.cpp:971-983) */
+RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec)
 {
-    int parent = P.f_parent[f];
-    if (parent >= 0) {
-        spec_store((flags & FR_SLOT2) ? P.f_c2 : P.f_c1, P.fcap, parent, R);
-        return;
-    }
-    int root = P.f_root[f];
     if (out_spec) for (int k = 0; k < RT_NSPEC; k++) out_spec[(size_t)root * RT_NSPEC + k] = R.v[k];
     if (out_rgb) {
         float r = 0.0f, g = 0.0f, b = 0.0f;
@@ -925,6 +1175,16 @@ RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags
         }
         out_rgb[(size_t)root * 3] = r; out_rgb[(size_t)root * 3 + 1] = g; out_rgb[(size_t)root * 3 + 2] = b;
     }
+}
+/* hand a frame's finished radiance to its parent (Shade.cpp:491-501) or, for a root, to the sample */
+RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec)
+{
+    int parent = P.f_parent[f];
+    if (parent >= 0) {
+        spec_store((flags & FR_SLOT2) ? P.f_c2 : P.f_c1, P.fcap, parent, R);
+        return;
+    }
+    sample_deliver(S, P.f_root[f], R, out_rgb, out_spec);
 }
 
 __global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
@@ -1592,4 +1852,8 @@ __global__ void __launch_bounds__(256) k_y4m_encode(const float *planes, int wid
     out[2 * plane + o] = (unsigned char)(int)Cr;
 }
 
+#ifdef RT_ONLY_FAST     /* tools/kernel_usage.sh: a quick look at one kernel's registers without building the whole library */
+template __global__ void k_fast<1>(const RtDevScene, RtSampleGrid, RtPipe, int64_t, float *, float *);
+#else
 #include "rt_api.inc"
+#endif

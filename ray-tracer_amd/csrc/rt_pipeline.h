@@ -28,9 +28,14 @@ enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT 
    atomics on one line serialise in its L2 channel whichever word they touch */
 #define CTR_LINE 32
 /* CTR_SHADOW and CTR_SLOW_V are the two halves of one 64-bit word: k_visual bumps both with a single atomic (wave_alloc2) */
+/* CTR_FAST: entries of the fast queue (k_generate_cull -> k_fast), CTR_WORK_F: k_fast's work counter; CTR_SNAP: values a
+   one-thread kernel (k_level_snap) copies between the stages of a level so that the next kernels of the stream read their
+   bounds from the device instead of waiting for the host: [0] the level's last frame + 1, [1] its shadow rays (clamped to
+   the queue).  CTR_OVERFLOW is cleared once per render call, everything else once per pass (k_pass_begin). */
 enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * CTR_LINE, CTR_SLOW_V = 2 * CTR_LINE + 1, CTR_SLOW_S = 4 * CTR_LINE,
        CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
-       CTR_COUNT = 10 * CTR_LINE };
+       CTR_FAST = 10 * CTR_LINE, CTR_WORK_F = 11 * CTR_LINE, CTR_SNAP = 12 * CTR_LINE, CTR_WORK_SH = 13 * CTR_LINE,
+       CTR_COUNT = 14 * CTR_LINE };
 #define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
 #ifndef RT_CLAIM
 #define RT_CLAIM 128        /* items a persistent wave claims per atomic: two 64-item passes.  Same box, 4K / 64 spp: 512 / 256 / 128 / 64 items =
@@ -55,6 +60,11 @@ typedef struct RtPipe {
     float  *s_E;                /* 10 */
     int    *slow_v, *slow_s;    /* frames / shadow rays the LITE kernels handed to the FULL ones: fcap, scap */
     int    *counters;           /* CTR_COUNT */
+    /* the fast queue: primary rays that can touch ONE child of the root union region, a bare chain of a two-root primitive
+       without rare features (RtDevScene.root_fast).  An entry is the sample (index within the pass) and the chain; k_fast
+       recomputes the ray from the sample index, keeps the (at most three) hits in registers and, where no shadow ray or
+       child ray is needed, shades and delivers the sample without ever making a frame.  2 x ncap ints: [k][chain]. */
+    int    *fast_q;
     /* the sampling tiles' candidate lists (RtSampleGrid::tile_mask / tile_cand) for the PRIMARY rays of this chunk: root
        sample k of the chunk lies in tile (tile_first + k) / 1600.  Null = none. */
     const unsigned char  *tile_n;

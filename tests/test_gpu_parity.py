@@ -745,3 +745,37 @@ def test_launch_and_staging_options_are_invisible(gpu, scene, name, off, on):
         assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0
     finally:
         L.rt_set_option(name.encode(), on)
+
+
+SCENE_POLISHED_ROW = SCENE_ROW.replace("plastic none none (sphere)", "plastic none none (surface polished none (sphere))")
+
+
+@pytest.mark.parametrize("scene", ["S0", SCENE_ROW, SCENE_POLISHED_ROW, SCENE_FOG_PERSPECTIVE], ids=["S0_inline", "row_shadow_frames", "row_polished_children", "fog_not_eligible"])
+def test_fast_path_is_invisible(gpu, scene):
+    """k_fast (primary rays that can touch ONE bare chain of the root region: no interpreter, no hit arena, hits in
+    registers; finished without a frame where no shadow ray or child ray is needed) against the interpreter path: scenes
+    uploaded with the option off and on render the same frames, bands and ray counts.  S0: its light casts no shadow,
+    so fast rays are shaded inline; the row of spheres under a shadow-casting light: fast rays become frames with shadow
+    rays; the polished row: frames with reflection children; the fog scene's big sphere has a propagator, its chains
+    are not eligible but the others are."""
+    L = gpu.rt_lib()
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    gpu.set_options({"fast_path": 0})
+    ref_scene = gpu.GpuScene(fs.desc)
+    gpu.set_options({"fast_path": 1})
+    fast_scene = gpu.GpuScene(fs.desc)
+    fast_total = 0
+    for (w, h, spp, r0, r1) in ((960, 540, 16, 0, 0), (480, 270, 16, 100, 171), (97, 131, 6.25, 0, 0), (64, 64, 1, 0, 0)):
+        a, sa = fast_scene.render(w, h, spp, row0=r0, row1=r1)
+        fast_total += sa.rays_fast
+        assert sa.rays_fast + sa.rays_visual0 <= sa.rays_primary
+        b, sb = ref_scene.render(w, h, spp, row0=r0, row1=r1)
+        assert np.array_equal(a, b), (w, h, spp)
+        assert (sa.rays_primary, sa.rays_shadow, sa.rays_secondary) == (sb.rays_primary, sb.rays_shadow, sb.rays_secondary)
+        assert sb.rays_fast == 0 and a.max() > 0
+    assert (fast_total > 0) == (scene is not SCENE_FOG_PERSPECTIVE)     # the fog sphere encloses everything: every ray can touch it, and it is not eligible
+    gpu.set_options({"level_sync": 1})              # the same passes with a host round trip per level
+    c, sc = fast_scene.render(480, 270, 16)
+    gpu.set_options({"level_sync": 0})
+    d, sd = fast_scene.render(480, 270, 16)
+    assert np.array_equal(c, d) and sc.rays() == sd.rays()
