@@ -339,9 +339,10 @@ RT_DEV void aux_load(const RtDevScene &S, const RtPipe &P, int root, double *aux
     if constexpr (!LITE) if (S.aux_tex) { aux[4] = P.aux[(size_t)4 * P.ncap + root]; aux[5] = P.aux[(size_t)5 * P.ncap + root]; }   /* LITE hands textured hits to FULL */
 }
 
-/* hint: bits 20..31 of a root frame's flags word = 1 + the ONE child of the root region the sample's tile can touch (0 = no
+/* hint: bits 21..31 of a root frame's flags word = 1 + the ONE child of the root region the sample's tile can touch (0 = no
    such statement): k_visual<.., TILES> then needs no tile lookups for the ray (FR_HINT_SHIFT, dropped by FR_KEEP_MASK) */
-#define FR_HINT_SHIFT 20
+#define FR_HINT_SHIFT 21
+#define FR_TRACED     (1 << 20) /* a level-0 frame k_fast has traced already (it needs shadow rays or children): k_visual passes over it */
 RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const DRay &r, const double *aux, int hint = 0)
 {
     d3_store(P.f_ray, P.fcap, 0, f, r.org);
@@ -380,11 +381,11 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleG
    workgroup run times). */
 #define RT_GEN_ITERS 6
 #define RT_GEN_SPAN  (RT_GEN_ITERS * 256)
-/* Survivors go one of two ways.  FAST: the sample's tile lists the children of the root region its rays can touch, the
-   (approximate, conservative) ray touches the box of exactly ONE of them, and that child is a bare chain of a two-root
-   primitive without rare features (RtDevScene.root_fast): the hit list of such a ray is that chain's list alone, at most
-   three hits, and k_fast handles it from (sample, chain) without a frame.  Everything else becomes a root frame for
-   k_visual as before.  Both queues are appended in sample order with one atomic per workgroup each. */
+/* Survivors go one of two ways.  FAST: the sample's tile lists the children of the root region its rays can touch, and
+   every child whose box the (approximate, conservative) ray touches is a bare chain of a two-root primitive without rare
+   features (RtDevScene.root_fast): k_fast handles such a ray from (sample, chain) or (sample, touched entries of the
+   tile's list) without a frame.  Everything else becomes a root frame for k_visual as before.  Both queues are appended
+   in sample order with one atomic per workgroup each. */
 __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, int n, const double *rays_org, const double *rays_dir,
                                                        const double *rays_aux, float *out_rgb, float *out_spec)
 {
@@ -396,12 +397,12 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
     const bool fast_on = S.root_fast && g.tile_cand && !rays_org;
     unsigned keep_bits = 0, fast_bits = 0;
     unsigned long long prefix = 0, prefix_f = 0;    /* 7 bits per iteration: survivors of that kind before this lane in its wave */
-    int fast_chain[RT_GEN_ITERS];
+    int fast_chain[RT_GEN_ITERS];       /* one chain (>= 0), or bit 31 + the touched entries of the tile's list */
 #pragma unroll
     for (int it = 0; it < RT_GEN_ITERS; it++) {
         int k = k0 + it * 256 + threadIdx.x;
         bool keep = false, fast = false;
-        fast_chain[it] = -1;
+        fast_chain[it] = 0;
         if (k < n) {
             k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
@@ -416,14 +417,22 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
                     const RtBox *cb = S.region_child_boxes + S.regions[S.root_cull_arg].child_pc0;
                     const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
                     if (fast_on) {
-                        int nh = 0, c1 = 0;
-                        for (int q = 0; q < tm && nh < 2; q++) if (cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr)) { nh++; c1 = tl[q]; }
-                        keep = nh > 0;
-                        if (nh == 1) { const int ch = S.root_fast[c1]; if (ch >= 0) { fast = true; keep = false; fast_chain[it] = ch; } }
+                        /* which listed children the ray can touch; k_fast takes the ray when every one of them is eligible */
+                        unsigned m = 0;
+                        bool elig = true;
+                        int c1 = 0;
+                        for (int q = 0; q < tm; q++)
+                            if (cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr)) { m |= 1u << q; c1 = S.root_fast[tl[q]]; elig = elig && c1 >= 0; }
+                        keep = m != 0;
+                        if (keep && elig) { fast = true; keep = false; fast_chain[it] = (m & (m - 1)) ? (int)(0x80000000u | m) : c1; }
                     } else
                         for (int q = 0; q < tm && !keep; q++) keep = cull_box_hit(cb[tl[q]].lo, cb[tl[q]].hi, cr);
-                } else
+                } else {
                     keep = scene_may_hit(S, lds, r, RT_INFINITY);
+#ifdef RT_NH_HIST
+                    if (keep) atomicAdd(&P.counters[CTR_PROF + 8], 1);
+#endif
+                }
             }
             if (!keep && !fast && !(masked && g.mask_skips_rgb)) {
                 if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
@@ -462,7 +471,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         int hint = 0;
         if (g.tile_mask && g.tile_cand && !rays_org) {
             const int64_t tile = (first + k) / RT_BLUE_N;
-            if (g.tile_mask[tile] == 1) { const int c = g.tile_cand[(size_t)tile * RT_TILE_CAND]; if (c < 4095) hint = c + 1; }
+            if (g.tile_mask[tile] == 1) { const int c = g.tile_cand[(size_t)tile * RT_TILE_CAND]; if (c < 2047) hint = c + 1; }
         }
         root_frame(S, P, block_base[0] + wave_base[0][it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux, hint);
     }
@@ -472,8 +481,12 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
    count to the number of root frames k_generate makes (0 when k_generate_cull counts them itself) */
 __global__ void k_pass_begin(int *counters, int frames0)
 {
-    for (int i = threadIdx.x; i < CTR_COUNT; i += blockDim.x)
+    for (int i = threadIdx.x; i < CTR_COUNT; i += blockDim.x) {
+#ifdef RT_NH_HIST
+        if (i >= CTR_PROF && i < CTR_PROF + CTR_LINE) continue;
+#endif
         if (i < CTR_OVERFLOW || i >= CTR_OVERFLOW + CTR_LINE) counters[i] = (i == CTR_FRAMES) ? frames0 : 0;
+    }
 }
 /* between the tracing kernels and the shading of a level: freeze the level's frame and shadow-ray counts where the next
    kernels of the stream read them (k_shade appends the next level's frames to CTR_FRAMES while it runs) */
@@ -715,7 +728,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     if (LITE && f1 < 0) {
         f1 = P.counters[CTR_FRAMES];
         if (f1 > P.fcap) f1 = P.fcap;
-        if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[CTR_SNAP + 2] = f1;     /* k_fast appends behind them: remembered for the statistics */
+        if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[CTR_SNAP + 2] = f1 - P.counters[CTR_FAST + 1];     /* for the statistics: the frames this kernel traces */
     }
     const bool direct = LITE || f1 > f0;
     const int n = direct ? (f1 - f0) : P.counters[CTR_SLOW_V];
@@ -732,7 +745,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     }
     const int wbase = wnext;
     wnext += 64;
-    const bool live = wbase + wlane < n;
+    bool live = wbase + wlane < n;
     int f;
     if (direct) f = f0 + wbase + wlane;
     else f = live ? P.slow_v[wbase + wlane] : 0;
@@ -744,8 +757,9 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     B.n_shadow = 0; B.mask = 0; B.bail = false;
     double aux[6];
     int flags = 0, root = 0;
+    const int flags_raw = live ? P.f_flags[f] : 0;
+    if (LITE && (flags_raw & FR_TRACED)) live = false;          /* k_fast's own level-0 frames, among the generator's */
     if (live) {
-        const int flags_raw = P.f_flags[f];
         flags = flags_raw & FR_KEEP_MASK;
         DRay ray;
         ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
@@ -852,6 +866,23 @@ RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, f
 /* MODE 1: the workgroup stages everything a fast ray looks up per lane -- chain records, the blue-noise tile and its two
    permutations, materials, surfaces -- in LDS (rt_scene_upload checks that it fits: S0 needs 117 KB); MODE 0: nothing is
    staged.  The loads below then are LDS instructions: the pointers are derived from the LDS base inside this function. */
+/* psModel->Intersect for a bare chain: affine, two-root primitive, wrappers; the (at most three) hits in registers */
+RT_DEV void fast_chain_hits(const RtDevScene &S, const RtChain &ch, const DRay &ray, RegEmit &H)
+{
+    DRay r = ray;
+    if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
+        DRay nr;
+        nr.dir = mat_vec(ch.minv, r.dir);
+        nr.org = mat_vec(ch.minv, r.org - d3(ch.tr[0], ch.tr[1], ch.tr[2]));
+        r = nr;
+    }
+    Work w;
+    if (ch.prim_op == OP_QUADRIC) quadric_roots(ch.p[0], ch.p[1], ch.p[2], ch.i0, r, w);
+    else if (ch.prim_op == OP_POLY) poly_roots(S.planes + 3 * (size_t)ch.plane0, ch.i0, r, w);
+    else slab_roots(r, w);
+    H.minv_own = (ch.test_box & RT_CHAIN_OWN_NORMAL) ? ch.minv : (const double *)0;
+    hit_list2_core(w, H, (uint16_t)ch.prim, ch.leaf_affine, &ch);
+}
 RT_HD size_t fast_lds_bytes(int n_chains, int n_mats, int n_surfs)
 {
     return (size_t)n_chains * sizeof(RtChain) + (size_t)2 * RT_BLUE_N * sizeof(double) + (size_t)2 * RT_BLUE_N * sizeof(int32_t) +
@@ -895,14 +926,14 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
     B.n_shadow = 0; B.mask = 0; B.bail = false; B.flags = 0;
     double aux[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };    /* only the light pair is ever read here (no aperture camera, no texture call-out on this path) */
     int k = 0;
-    bool need_frame = false;
+    bool need_frame = false, hand_over = false;
+    DRay ray;
     if (live) {
         k = nt_load(&P.fast_q[e]);
-        const int ci = nt_load(&P.fast_q[(size_t)P.ncap + e]);
-        DRay ray;
+        const int code = nt_load(&P.fast_q[(size_t)P.ncap + e]);
+        const int64_t sidx = first + k;
+        const uint32_t tile = (uint32_t)(sidx / RT_BLUE_N);
         {   /* FastBlueSamplingTile::Render, Sampling.cpp:498-517 + CastFunction, RayTracer2020.cpp:20-31: as sample_at / root_ray */
-            const int64_t sidx = first + k;
-            const uint32_t tile = (uint32_t)(sidx / RT_BLUE_N);
             const int i = (int)(sidx - (int64_t)tile * RT_BLUE_N);
             const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
             const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
@@ -916,23 +947,39 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
             }
             ray = camera_emit(S.cam, v0, v1, 0.0, 0.0);
         }
-        const RtChain &ch = chains[ci];
-        DRay r = ray;
-        if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
-            DRay nr;
-            nr.dir = mat_vec(ch.minv, r.dir);
-            nr.org = mat_vec(ch.minv, r.org - d3(ch.tr[0], ch.tr[1], ch.tr[2]));
-            r = nr;
-        }
-        Work w;
-        if (ch.prim_op == OP_QUADRIC) quadric_roots(ch.p[0], ch.p[1], ch.p[2], ch.i0, r, w);
-        else if (ch.prim_op == OP_POLY) poly_roots(S.planes + 3 * (size_t)ch.plane0, ch.i0, r, w);
-        else slab_roots(r, w);
         RegEmit H;
-        H.minv_own = (ch.test_box & RT_CHAIN_OWN_NORMAL) ? ch.minv : (const double *)0;
-        hit_list2_core(w, H, (uint16_t)ch.prim, ch.leaf_affine, &ch);
-        visual_walk<true>(S, ray, aux, H, H.L, B, K);
-        if (B.bail) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL); B.n_shadow = 0; B.mask = 0; }
+        H.L = 0; H.minv_own = 0;
+        if (code >= 0) {
+            /* ONE chain can be touched: its list is the ray's hit list */
+            fast_chain_hits(S, chains[code], ray, H);
+        } else {
+            /* Several chains can be touched.  Their lists would be merged by the union's density lattice (Solids.cpp:1014-
+               1058) and the walk would stop at the first boundary (Shade.cpp:443).  When every list starts ahead of the
+               origin (no t = 0 hit: the origin is outside them all), the merged list starts with the nearest of their first
+               hits, entering that hit's own material (the other lists still are in vacuum there) -- provided that material
+               is denser than vacuum (else the merge drops the hit) and no second list has a first hit at exactly the same
+               distance (a tie takes the left record and the denser material).  If the walk then stops at that hit, nothing
+               behind it matters: the ray is finished from that one hit.  Anything else is handed to the interpreter. */
+            const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
+            double t_best = RT_INFINITY, t_next = RT_INFINITY;
+            for (unsigned m = (unsigned)code & 0xFFu; m; m &= m - 1) {
+                const RtChain &ch = chains[S.root_fast[tl[__builtin_ctz(m)]]];
+                RegEmit T;
+                fast_chain_hits(S, ch, ray, T);
+                if (T.L == 0) continue;
+                const double t = T.h0.t;
+                if (!(t > 0.0)) { hand_over = true; break; }
+                if (t < t_best) { t_next = t_best; t_best = t; H.h0 = T.h0; H.minv_own = T.minv_own; H.L = 1; }
+                else if (t < t_next) t_next = t;
+            }
+            if (H.L == 1 && (t_next == t_best || !(S.mats[H.h0.mat].density > 0.0))) hand_over = true;
+        }
+        if (!hand_over) {
+            visual_walk<true>(S, ray, aux, H, H.L, B, K);
+            if (code < 0 && H.L == 1 && !B.bail && !(B.flags & FR_BOUNDARY)) hand_over = true;      /* the walk went on past the hit */
+        }
+        if (hand_over) { B.n_shadow = 0; B.mask = 0; }
+        else if (B.bail) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL); B.n_shadow = 0; B.mask = 0; }
         else if ((B.flags & FR_BOUNDARY) && (B.n_shadow > 0 || K.rough == RT_SURF_POLISHED)) need_frame = true;
         else {
             Spec R = B.R;
@@ -941,16 +988,20 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
             sample_deliver(S, k, R, out_rgb, out_spec);
         }
     }
-    /* the lanes that could not finish become level-0 frames behind the generator's (k_visual has run by now) */
-    if (__ballot(need_frame) == 0ull) continue;
-    const int f = wave_alloc(need_frame ? 1 : 0, &P.counters[CTR_FRAMES]);
+    /* the lanes that could not finish become level-0 frames behind the generator's: traced ones (FR_TRACED: the record
+       k_visual would have stored, for k_shade) and root frames for the interpreter (k_visual runs behind this kernel) */
+    const unsigned long long bt = __ballot(need_frame), bh = __ballot(hand_over);
+    if ((bt | bh) == 0ull) continue;
+    const int f = wave_alloc((need_frame || hand_over) ? 1 : 0, &P.counters[CTR_FRAMES]);
     const int base = wave_alloc(need_frame ? B.n_shadow : 0, &P.counters[CTR_SHADOW]);
-    if (!need_frame || f >= P.fcap) continue;               /* a full pool is reported by the host from the counter */
+    if (wlane == 0 && bt) atomicAdd(&P.counters[CTR_FAST + 1], __popcll(bt));
+    if (!(need_frame || hand_over) || f >= P.fcap) continue;               /* a full pool is reported by the host from the counter */
     aux[4] = aux[2]; aux[5] = aux[3];                       /* the micro-facet pair follows the light's permutation (Sampling.cpp:512-515) */
+    if (hand_over) { root_frame(S, P, f, k, ray, aux, 0); continue; }
     aux_store(S, P, k, aux);
     P.f_parent[f] = -1;
     P.f_root[f] = k;
-    FrameSink FS = { P, f, 0 };
+    FrameSink FS = { P, f, FR_TRACED };
     if (B.flags & FR_BOUNDARY) FS.boundary(B.P, K.N, K.E, K.HN, K.fNE, K.F, K.fNT, K.eta, K.rough, K.luster, K.mat, K.color, K.color_is_mat);
     const int flags = frame_finish<true>(P, f, B, FS.flags);
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
@@ -1072,13 +1123,17 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
 RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags, const Spec &R, float *out_rgb, float *out_spec);
 
 /* ------------------------------------------------------------------ k_shade: light loop + child rays (Shade.cpp:477-501)
- * Frames [f0, f1) of one level, grid-stride (the host launches a few workgroups per CU whatever the count); f1 < 0: the
- * level's end is on the device (CTR_SNAP, written by k_level_snap behind the tracing kernels). */
+ * Frames [f0, f1) of one level, one per thread; f1 < 0: the level's end is on the device (CTR_SNAP, written by k_level_snap
+ * behind the tracing kernels) and the host has launched for an upper bound -- workgroups beyond the end leave at once.
+ * (A grid-stride loop over the frames made the compiler hoist per-frame address arithmetic out of it and spill 308 B per
+ * lane at three waves per SIMD: 2.3 x slower per frame.) */
 __global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
 {
     const RtDevScene &S = Sv;
     if (f1 < 0) f1 = P.counters[CTR_SNAP];
-  for (int fb = f0 + blockIdx.x * 256; fb < f1; fb += gridDim.x * 256) {
+  {
+    const int fb = f0 + blockIdx.x * 256;
+    if (fb >= f1) return;
     const int f = fb + threadIdx.x;
     const bool live = f < f1;
     int nchild = 0, flags = 0;
@@ -1141,7 +1196,7 @@ __global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P,
         }
     }
     int base = wave_alloc(nchild, &P.counters[CTR_FRAMES]);
-    if (!live || nchild == 0) continue;
+    if (!live || nchild == 0) return;
     int c = base;
     for (int which = 0; which < 2; which++) {
         if (which == 0 ? !want_refl : !want_refr) continue;
