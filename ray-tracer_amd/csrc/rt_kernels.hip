@@ -341,6 +341,7 @@ RT_DEV void aux_load(const RtDevScene &S, const RtPipe &P, int root, double *aux
 
 /* hint: bits 21..31 of a root frame's flags word = 1 + the ONE child of the root region the sample's tile can touch (0 = no
    such statement): k_visual<.., TILES> then needs no tile lookups for the ray (FR_HINT_SHIFT, dropped by FR_KEEP_MASK) */
+#define RT_BOUND_ON_DEVICE (1 << 29)    /* in k_visual's n_chains_lds argument: see there */
 #define FR_HINT_SHIFT 21
 #define FR_TRACED     (1 << 20) /* a level-0 frame k_fast has traced already (it needs shadow rays or children): k_visual passes over it */
 RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const DRay &r, const double *aux, int hint = 0)
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
     const SceneLds lds = scene_lds_load(S, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = blockIdx.x * RT_GEN_SPAN;
-    const bool fast_on = S.root_fast && g.tile_cand && !rays_org;
+    const bool fast_on = S.root_fast && P.tile_cand && !rays_org;       /* the host runs k_fast and the tile-list build of k_visual together */
     unsigned keep_bits = 0, fast_bits = 0;
     unsigned long long prefix = 0, prefix_f = 0;    /* 7 bits per iteration: survivors of that kind before this lane in its wave */
     int fast_chain[RT_GEN_ITERS];       /* one chain (>= 0), or bit 31 + the touched entries of the tile's list */
@@ -498,7 +499,7 @@ __global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
         P.counters[CTR_SNAP + 1] = ns < P.scap ? ns : P.scap;
         if (level0) {           /* measurement: how the call's primary rays were traced (the line outlives the pass) */
             P.counters[CTR_OVERFLOW + 2] += P.counters[CTR_FAST];
-            P.counters[CTR_OVERFLOW + 3] += gen_frames < 0 ? P.counters[CTR_SNAP + 2] : gen_frames;
+            P.counters[CTR_OVERFLOW + 3] += (gen_frames < 0 ? nf : gen_frames) - P.counters[CTR_FAST + 1];     /* level-0 frames k_visual traced: all but k_fast's own */
         }
     }
 }
@@ -599,7 +600,11 @@ RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux,
     bool bail = false;
     for (; i < count && !bail; i++) {
         ShadeHit h;
+#ifdef RT_Z2
+        transform_normals<LITE>(S, ray, H.get(i), h, aux, bail);
+#else
         transform_normals<LITE>(S, ray, H.get(i), h, aux, bail, H.own_minv());
+#endif
         if (bail) break;
         const RtMaterialDev &mp = S.mats[pm];
         int mp_luster = mp.luster;
@@ -682,7 +687,8 @@ RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux,
         }
     }
     B.bail = bail;
-    B.R = R; B.tr = tr;
+    B.R = R;
+    if constexpr (!LITE) B.tr = tr;
 }
 
 /* what is left of a frame record after the walk: radiance and transmittance, as flags where a flag says it all (bytes
@@ -696,23 +702,26 @@ RT_DEV int frame_finish(const RtPipe &P, const int f, const Walk &B, int flags)
     return flags;
 }
 /* the shadow rays of a stored frame: slots [base, base + n_shadow) of the queue, in light order */
-RT_DEV void shadow_append(const RtDevScene &S, const RtPipe &P, const Walk &B, const int base, const int root, const double *aux)
+RT_DEV void shadow_append(const RtDevScene &S, const RtPipe &P, const D3 &Ppt, const unsigned mask, const int base, const int root, const double *aux)
 {
     int k = 0;
     for (int li = 0; li < S.n_lights; li++) {
-        if (!(B.mask & (1u << li))) continue;
+        if (!(mask & (1u << li))) continue;
         int s = base + k++;
         if (s >= P.scap) continue;          /* overflow is reported by the host from the counter */
         const RtLightDev &l = S.lights[li];
         D3 lo = d3(l.org[0], l.org[1], l.org[2]);
         if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
-        d3_store(P.s_ray, P.scap, 0, s, B.P);
-        d3_store(P.s_ray, P.scap, 3, s, lo - B.P);
+        d3_store(P.s_ray, P.scap, 0, s, Ppt);
+        d3_store(P.s_ray, P.scap, 3, s, lo - Ppt);
         P.s_light[s] = li;
         P.s_root[s] = root;
     }
 }
 
+/* The walk below is written out in this kernel (and again, as visual_walk, for k_fast): routed through the shared function
+   the interpreter kernels spill 300 B more per lane and S1 / S2 render 6-7 % slower (same box, alternating: S2 483 against
+   454 ms, S1 361 against 338).  Every parity test runs both copies against the oracle. */
 template <bool LITE, int MODE, bool TILES = false>
 __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
@@ -722,16 +731,14 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     const RtDevScene &S = SL;
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
-    /* LITE, f1 < 0: the root frames k_generate_cull made -- their number is on the device (no kernel of the stream changes it
-       while this one runs).  FULL: over the slow list the LITE launch left, or (f1 > f0: a small level, no LITE launch
-       before it) over the frames themselves */
-    if (LITE && f1 < 0) {
-        f1 = P.counters[CTR_FRAMES];
-        if (f1 > P.fcap) f1 = P.fcap;
-        if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[CTR_SNAP + 2] = f1 - P.counters[CTR_FAST + 1];     /* for the statistics: the frames this kernel traces */
-    }
+    /* LITE && TILES (the primary level of a pass with tile lists) with RT_BOUND_ON_DEVICE in n_chains_lds: [f0, f1) is an
+       upper bound, the level's real end is on the device (CTR_FRAMES: no kernel of the stream changes it while this one
+       runs) and is looked at with every claim.  Only in the TILES builds: the code costs the interpreter 300 B of spills
+       per lane wherever it is compiled in (S1 / S2, which never use it, rendered 6 % slower with it).  FULL: over the
+       slow list the LITE launch left, or (f1 > f0: a small level, no LITE launch before it) over the frames themselves */
     const bool direct = LITE || f1 > f0;
     const int n = direct ? (f1 - f0) : P.counters[CTR_SLOW_V];
+    const bool dev_bound = LITE && TILES && (n_chains_lds & RT_BOUND_ON_DEVICE);
     int *const work = &P.counters[LITE ? CTR_WORK_V : CTR_WORK_VS];
     const int wlane = threadIdx.x & 63;
   int wnext = 0, wlimit = 0;      /* the wave's current claim: items [wnext, wlimit) */
@@ -741,30 +748,40 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         if (wlane == 0) b = atomicAdd(work, RT_CLAIM);
         b = __shfl(b, 0, 64);
         if (b >= n) break;
-        wnext = b; wlimit = b + RT_CLAIM < n ? b + RT_CLAIM : n;
+        int lim = n;
+        if constexpr (LITE && TILES) if (dev_bound) {
+            lim = __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(&P.counters[CTR_FRAMES])) - f0;
+            if (lim > n) lim = n;
+            if (b >= lim) break;
+        }
+        wnext = b; wlimit = b + RT_CLAIM < lim ? b + RT_CLAIM : lim;
     }
     const int wbase = wnext;
     wnext += 64;
-    bool live = wbase + wlane < n;
+    bool live = wbase + wlane < wlimit;
     int f;
     if (direct) f = f0 + wbase + wlane;
     else f = live ? P.slow_v[wbase + wlane] : 0;
+    if constexpr (LITE && TILES) {      /* level 0 of a pass with tile lists: k_fast's own (traced) frames lie among the generator's */
+        if (live && (P.f_flags[f] & FR_TRACED)) live = false;
+    }
 #ifdef RT_PHASE_PROF
     long long prof_t0 = clock64();
     int prof_v[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
-    Walk B;
-    B.n_shadow = 0; B.mask = 0; B.bail = false;
+    int n_shadow = 0;
+    unsigned mask = 0;
+    D3 Ppt = d3(0, 0, 0);
     double aux[6];
-    int flags = 0, root = 0;
-    const int flags_raw = live ? P.f_flags[f] : 0;
-    if (LITE && (flags_raw & FR_TRACED)) live = false;          /* k_fast's own level-0 frames, among the generator's */
+    int flags = 0;
+    bool bail = false;
     if (live) {
+        const int flags_raw = P.f_flags[f];
         flags = flags_raw & FR_KEEP_MASK;
         DRay ray;
         ray.org = d3_fetch(P.f_ray, P.fcap, 0, f);
         ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
-        root = P.f_root[f];
+        int root = P.f_root[f];
         aux_load<LITE>(S, P, root, aux);
         Arena A;
         int start;
@@ -781,27 +798,129 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         }
         int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
+        bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
         for (int q = 1; q < 8; q++) prof_v[q] = A.prof[q];
         prof_v[8] = (int)(clock64() - prof_t0);
 #endif
-        if (A.bail) B.bail = true;
-        else {
-            const ArenaHits H = { A, start };
-            FrameSink K = { P, f, flags };
-            visual_walk<LITE>(S, ray, aux, H, count, B, K);
-            if (!B.bail) flags = frame_finish<LITE>(P, f, B, K.flags);
+        /* Shade.cpp:424-432: regularise into (0, t, ...) */
+        int i = 0, pm = 0;
+        if (count > 0 && !(A.h[start].t > 0.0)) { pm = A.h[start].mat; i = 1; }
+        double t = 0.0;
+        Spec tr = spec_const(1.0f), R = spec_const(0.0f);
+        int r_state = 0;                /* 0: R is zero, 1: R is the boundary's ambient term alone, 2: anything else */
+        bool tr_one = true;
+        /* Q13: colour / luster a solid texture gave the material the walk is inside of (FULL kernel only: LITE hands
+           textured hits over) */
+        int pm_luster_ov = -1, pm_has_color = 0;
+        Spec pm_color = spec_const(0.0f);
+        for (; i < count && !bail; i++) {
+            ShadeHit h;
+            transform_normals<LITE>(S, ray, A.h[start + i], h, aux, bail);
+            if (bail) break;
+            const RtMaterialDev &mp = S.mats[pm];
+            int mp_luster = mp.luster;
+            const float *mp_colorp = mp.color;
+            if constexpr (!LITE) { if (pm_luster_ov >= 0) mp_luster = pm_luster_ov; if (pm_has_color) mp_colorp = pm_color.v; }
+            if (mp_luster == RT_MAT_NOSHADE) {                  /* Shade.cpp:436-437 (Q2: no depth leak) */
+                R = spec_load(mp_colorp);
+                r_state = 2;
+                flags |= FR_FINAL;
+                break;
+            }
+            if (mp.prop) {
+                if constexpr (LITE) { bail = true; break; }
+                else {
+                    Spec ptr, pst;
+                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
+                    tr = tr * ptr;
+                    R = R + pst;
+                    r_state = 2; tr_one = false;
+                }
+            }
+            const RtMaterialDev &mh = S.mats[h.mat];
+            int mh_luster = mh.luster;
+            if constexpr (!LITE) if (h.luster_ov >= 0) mh_luster = h.luster_ov;
+            if ((mp.refr != mh.refr) || (mh_luster != RT_MAT_TRANSPARENT)) {
+                D3 vE, cvN;
+                double fNE, F = 0.0, fNT = 0.0;
+                consistent_normal(ray, h, vE, cvN, fNE);
+                Spec color = spec_load(mh.color);
+                bool color_is_mat = true;
+                if constexpr (!LITE) if (h.has_color) { color = h.color; color_is_mat = false; }
+                if (spectral_metal(mh_luster)) {                /* Q3 */
+                    if constexpr (LITE) { bail = true; break; }
+                    else {
+                        color = fresnel_spectral(fNE, mp.refr, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC, S.metal_nk + (size_t)mh_luster * 2 * RT_NSPEC + RT_NSPEC);
+                        F = 1.0;
+                        color_is_mat = false;
+                    }
+                } else
+                    fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
+                int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
+                if (S.has_ambient && rough != RT_SURF_POLISHED) {
+                    Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
+                    R = R + color * E;
+                    r_state = (r_state == 0 && color_is_mat) ? 1 : 2;
+                }
+                Ppt = ray_at(ray, h.t);
+                /* which lights get a shadow ray (Shade.cpp:477-481) */
+                for (int li = 0; li < S.n_lights; li++) {
+                    const RtLightDev &l = S.lights[li];
+                    D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+                    if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+                    D3 dir = lo - Ppt;
+                    if (dot(cvN, dir) <= 0.0 && mh_luster != RT_MAT_TRANSPARENT) continue;
+                    if (l.no_shadow) continue;
+                    mask |= 1u << li;
+                    n_shadow++;
+                }
+                flags |= FR_BOUNDARY;
+                if (h.perturbed) flags |= FR_PERTURBED;
+                d3_store(P.f_geo, P.fcap, GEO_P, f, Ppt);
+                d3_store(P.f_geo, P.fcap, GEO_N, f, cvN);
+                d3_store(P.f_geo, P.fcap, GEO_E, f, vE);
+                d3_store(P.f_geo, P.fcap, GEO_HN, f, h.n);
+                P.f_geo[(size_t)GEO_FNE * P.fcap + f] = fNE;
+                P.f_geo[(size_t)GEO_F * P.fcap + f] = F;
+                P.f_geo[(size_t)GEO_FNT * P.fcap + f] = fNT;
+                P.f_geo[(size_t)GEO_ETA * P.fcap + f] = mp.refr / mh.refr;
+                P.f_ids[(size_t)IDS_ROUGH * P.fcap + f] = rough;
+                P.f_ids[(size_t)IDS_LUSTER * P.fcap + f] = mh_luster | ((int)h.mat << 8);
+                if (color_is_mat) flags |= FR_COLOR_MAT; else spec_store(P.f_color, P.fcap, f, color);
+                t = h.t;
+                pm = h.mat;
+                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
+                break;
+            } else {
+                t = h.t;
+                pm = h.mat;
+                if constexpr (!LITE) { pm_luster_ov = h.luster_ov; pm_has_color = h.has_color; pm_color = h.color; }
+            }
+        }
+        if (!bail && !(flags & FR_FINAL) && S.mats[pm].prop) {  /* Shade.cpp:512-516 */
+            if constexpr (LITE) bail = true;
+            else {
+                Spec ptr, pst;
+                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
+                spec_store(P.f_fin, P.fcap, f, tr * pst);
+                flags |= FR_FIN;
+            }
+        }
+        if (!bail) {
+            if (r_state == 0) flags |= FR_R_ZERO; else if (r_state == 1) flags |= FR_R_AMBIENT; else spec_store(P.f_R, P.fcap, f, R);
+            if (tr_one) flags |= FR_TR_ONE; else spec_store(P.f_tr, P.fcap, f, tr);
         }
     }
     /* append this lane's shadow rays to the queue and (LITE) the frame to the slow list: one atomic per wave for both */
     int base;
     if constexpr (LITE) {
-        if (B.bail) { B.n_shadow = 0; B.mask = 0; }
+        if (bail) { n_shadow = 0; mask = 0; }
         int slot;
-        wave_alloc2(B.n_shadow, B.bail ? 1 : 0, &P.counters[CTR_SHADOW], base, slot);
-        if (B.bail) P.slow_v[slot] = f;
+        wave_alloc2(n_shadow, bail ? 1 : 0, &P.counters[CTR_SHADOW], base, slot);
+        if (bail) P.slow_v[slot] = f;
     } else
-        base = wave_alloc(B.n_shadow, &P.counters[CTR_SHADOW]);
+        base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
     for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 1024 cycles (int counters: 16 overflowed on long frames) */
@@ -810,11 +929,25 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 10);
     }
 #endif
-    if (!live || B.bail) continue;
+    if (!live || bail) continue;
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
-    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)B.mask;
+    P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)mask;
     P.f_flags[f] = flags;
-    if (B.n_shadow) shadow_append(S, P, B, base, root, aux);
+    if (n_shadow) {
+        int k = 0;
+        for (int li = 0; li < S.n_lights; li++) {
+            if (!(mask & (1u << li))) continue;
+            int s = base + k++;
+            if (s >= P.scap) continue;          /* overflow is reported by the host from the counter */
+            const RtLightDev &l = S.lights[li];
+            D3 lo = d3(l.org[0], l.org[1], l.org[2]);
+            if (l.type == RT_LIGHT_AREA) lo = lo + d3(l.vA[0], l.vA[1], l.vA[2]) * aux[2] + d3(l.vB[0], l.vB[1], l.vB[2]) * aux[3];
+            d3_store(P.s_ray, P.scap, 0, s, Ppt);
+            d3_store(P.s_ray, P.scap, 3, s, lo - Ppt);
+            P.s_light[s] = li;
+            P.s_root[s] = P.f_root[f];
+        }
+    }
   }
 }
 
@@ -1007,7 +1140,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
     P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
     P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)B.mask;
     P.f_flags[f] = flags;
-    if (B.n_shadow) shadow_append(S, P, B, base, k, aux);
+    if (B.n_shadow) shadow_append(S, P, B.P, B.mask, base, k, aux);
   }
 }
 
@@ -1907,8 +2040,11 @@ __global__ void __launch_bounds__(256) k_y4m_encode(const float *planes, int wid
     out[2 * plane + o] = (unsigned char)(int)Cr;
 }
 
-#ifdef RT_ONLY_FAST     /* tools/kernel_usage.sh: a quick look at one kernel's registers without building the whole library */
+#if defined(RT_ONLY_FAST)     /* tools/kernel_usage.sh: a quick look at one kernel's registers without building the whole library */
 template __global__ void k_fast<1>(const RtDevScene, RtSampleGrid, RtPipe, int64_t, float *, float *);
+#elif defined(RT_ONLY_VISUAL)
+template __global__ void k_visual<true, 2, false>(const RtDevScene, RtPipe, int, int, int);
+template __global__ void k_visual<true, 1, true>(const RtDevScene, RtPipe, int, int, int);
 #else
 #include "rt_api.inc"
 #endif
