@@ -9,10 +9,13 @@ k is queued asynchronously and runs beside the render of frame k + 1 into a seco
 for before the clock stops).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S0|S1|S2|S4|S4@t|MESH100K|MESH1M|MESH10M|"(scene ...)"] [--width W --height H --spp S]
-                  [--no-cpu-baseline]
+                  [--frames F] [--no-cpu-baseline]
 
 Default workload = BASELINE.json configs[1]: the as-checked-in TestScene.cpp scene ("S0": 257 spheres,
 MakeLightsLorenz, stereographic camera) at 3840x2160, 64 spp FastBlue = 530,841,600 samples.
+--frames F (BASELINE configs[4], "frame- and tile-parallel"): a step is a batch of F frames PER RANK of Laboratory()'s
+animation (LaboratoryAnimation.cpp:410-436), whole frames dealt round robin to the ranks, finished frames collected on
+rank 0 inside the timed region; per-GPU work is fixed as N grows ("scaling": "weak").
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -27,12 +30,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work of the dominant kernel (k_visual), SURVEY.md section 8d weights, flops per event
+# algorithmic work of a traced ray, SURVEY.md section 8d weights, flops per event
 W_AFFINE, W_QUADRIC, W_BOX, W_MERGE, W_SHADE, W_SHADE_LIGHT = 33.0, 57.0, 30.0, 6.0, 250.0, 60.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = half of the 157.3 TF FP32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
-# PMC measurement of the same workload (a copy of profiles/r01_m_pmc_traffic_k_visual.json kept where GPU runs can read it)
-TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic_k_visual.json")
+# PMC measurement of the same workload, collected by tools/pmc_traffic.sh in runs of their own (a copy of the profiles/
+# file named inside, kept where GPU runs can read it): NOT measured by this run
+TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic.json")
 
 
 # BASELINE configs[3]: a synthetic mesh of about ten million triangles (a lobed, star-shaped closed surface of
@@ -66,6 +70,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=float, default=64.0)
+    ap.add_argument("--frames", type=int, default=0, help="frame-parallel animation: frames of Laboratory() per rank and step (0 = one frame split by rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opts", default=os.environ.get("RT_OPTS", ""), help="library tunables for A/B runs: name=value,...")
     args = ap.parse_args()
@@ -97,6 +102,8 @@ def main():
         name, val = kv.split("=")
         if rt.rt_lib().rt_set_option(name.encode(), int(val)):
             raise SystemExit("bad --opts entry %r" % kv)
+    if args.frames > 0:
+        return frames_mode(args, rt, torch, dist, world, rank, rehearse)
     W, H, spp = args.width, args.height, args.spp
     scene_name = args.scene
     args.scene = NAMED_SCENES.get(scene_name, scene_name)
@@ -144,21 +151,21 @@ def main():
         step()
     drain()
     note("warmup done")
-    rt.rt_lib().rt_set_option(b"time_kernels", 1)      # HIP events around every k_visual launch of the timed region
+    # HIP events around the tracing kernels' launches of the timed region, recorded on the render stream and read back
+    # after it (rt_probe_work / rt_probe_fast_time): nothing inside the region waits for them
+    rt.rt_lib().rt_set_option(b"time_kernels", 1)
     barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    rays = samples = 0
+    rays = samples = rays_fast = rays_interp = 0
     t_trace = 0.0
     for _ in range(args.steps):
         st = step()
         rays += st.rays()
         samples += st.samples
+        rays_fast += st.rays_fast
+        rays_interp += st.rays_visual0
         t_trace += st.seconds_trace
     drain()                 # the last frame's gather belongs to the timed region
-    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
     note("timed steps done")
@@ -178,34 +185,115 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64, configs[3] when MESH10M)" % (scene_name, W, H, spp),
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
-                       "rays_per_step": rays_all / args.steps, "rays_fast_per_step": st.rays_fast, "rays_interpreter_level0_per_step": st.rays_visual0,
-                       "parallelism": "rows%d" % world, "bands": rows,
+                       "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows,
+                       # how rank 0's primary rays were traced: the rest ended in the generator (they miss every box of the scene)
+                       "primary_rays_per_step_by_path": {"k_fast": rays_fast / args.steps, "k_visual": rays_interp / args.steps,
+                                                          "ended_in_generator": (st.rays_primary - st.rays_fast - st.rays_visual0)},
                        **({"rehearsal": "all ranks on one GPU, gloo"} if rehearse else {})},
             "sec_per_frame": dt / args.steps,
         }
-        res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, t_trace, res["config"]["workload"])
+        res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, rays_fast, res["config"]["workload"])
         if scene_name.startswith("MESH"):
-            res["roofline"]["note"] = ("mesh workload: 88 % of the GPU time is the mesh walk inside the FULL k_shadow / k_visual launches "
-                                       "(profiles/r01_h_MESH10M_4k64_kernel_stats.csv), latency-bound on divergent 128-byte BVH node and 80-byte "
-                                       "triangle reads (about 15 nodes + 11 triangles = 2.8 KB per mesh ray, tools/mesh_count.py); the figures in "
-                                       "this object are the frame-record bytes of the timed k_visual launches only")
+            res["roofline"]["note"] = ("mesh workload: most of the GPU time is the mesh walk inside the FULL k_shadow / k_visual launches, "
+                                       "latency-bound on divergent 128-byte BVH node and 80-byte triangle reads (about 15 nodes + 11 triangles = "
+                                       "2.8 KB per mesh ray, tools/mesh_count.py); the figures in this object are the frame-record bytes of the "
+                                       "timed k_visual launches only")
         note("roofline probe done")
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(ge, rt, args.scene, scene_name)
+            res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_baseline(ge, rt, args.scene, scene_name)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 
 
-def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total, workload):
-    """Dominant kernel = k_visual (intersection + boundary shading of every visual ray).  Its nearest hard roof is HBM:
-    a wavefront kernel streams one frame record per ray.  achieved = ALGORITHMIC bytes per launch / average launch
-    duration: per ray 56 B read (ray, flags, root) + 16 B per auxiliary pair the scene needs (area light -> 1) + 4 B
-    flags written, + 144 B (geometry 128 + ids 16) per shaded boundary, + 56 B per shadow ray queued (DESIGN.md section
-    6); the duration is measured with HIP events on the kernel's own stream (option time_kernels).  traffic = HBM bytes
-    per launch from PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), when this is the
-    workload they were collected on.  The FP64-vector view of the same launches (SURVEY 8d's per-event flop weights x
-    IDEAL-culling event counts, counted by the device on a sample of the workload's camera rays) is in "valu_fp64"."""
+def frames_mode(args, rt, torch, dist, world, rank, rehearse):
+    """Frame-parallel animation (BASELINE configs[4] without its Atmosphere stub): every rank renders whole
+    frames of Laboratory() -- frame i of a batch goes to rank i % world -- and rank 0 collects them.  Scene construction,
+    Optimize() and upload are the reference driver's work outside RayTracer::Render (LaboratoryAnimation.cpp:412-432) and
+    happen before the clock starts.  Fixed work per GPU: weak scaling."""
+    sh = rt.sharding
+    times = sh.laboratory_times()
+    F, W, H, spp = args.frames, args.width, args.height, args.spp
+    per_step = F * world
+    need = (args.warmup + args.steps) * per_step
+    assign = sh.frame_assignment(per_step, world)
+    scenes = {}
+    for step_i in range(args.warmup + args.steps):
+        for j in assign[rank]:
+            gi = (step_i * per_step + j) % len(times)
+            if gi not in scenes:
+                fs = rt.FrontScene("S4@%.17g" % times[gi], "fastblue", optimize=True)
+                scenes[gi] = (fs, rt.GpuScene(fs.desc))
+    note("%d scenes built and uploaded on rank 0 (of %d frames in all)" % (len(scenes), need))
+    bufs = [torch.zeros((3, H, W), dtype=torch.float32, device="cuda") for _ in range(F)]
+    stream = torch.cuda.current_stream().cuda_stream
+    owner = {i: r for r in range(world) for i in assign[r]}
+
+    def step(step_i):
+        rays = samples = 0
+        mine = {}
+        for n, j in enumerate(assign[rank]):
+            gi = (step_i * per_step + j) % len(times)
+            st = scenes[gi][1].render_device(W, H, spp, bufs[n].data_ptr(), stream)
+            rays += st.rays()
+            samples += st.samples
+            mine[j] = bufs[n]
+        got = sh.gather_frames(mine, owner, rank, world, dist)
+        return rays, samples, len(got)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    rays = samples = 0
+    for k in range(args.steps):
+        r, s, _ = step(args.warmup + k)
+        rays += r
+        samples += s
+    barrier()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([float(rays), float(samples), dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[2])
+    if rank == 0:
+        res = {
+            "metric": "rays/sec (primary+secondary)", "value": float(tot[0]) / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Laboratory() animation, %d frames per rank and step, %dx%d %g spp FastBlue (BASELINE configs[4] without its Atmosphere stub)" % (F, W, H, spp),
+                       "scene": "S4@t", "width": W, "height": H, "spp": spp, "frames_per_step": per_step, "parallelism": "frames%d" % world,
+                       "rays_per_step": float(tot[0]) / args.steps, "samples_per_step": float(tot[1]) / args.steps,
+                       **({"rehearsal": "all ranks on one GPU, gloo"} if rehearse else {})},
+            "sec_per_frame": dt / (args.steps * per_step) * world,
+            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "note": "frame-parallel mode times whole frames; the kernel roofline is reported by the one-frame mode (--scene S4)"},
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
+    """The dominant kernel of the timed steps and its roofs.
+
+    S0-like workloads (most primary rays can only touch bare chains of the root region): k_fast.  It reads an 8-byte queue
+    entry per ray and writes 12 bytes of RGB -- ALGORITHMIC bytes = 20 per ray -- so against the HBM roof it is nowhere
+    (frac of a percent) and says so: the kernel is FP64 VALU work, which is what SURVEY 8d calls this path.  "valu_fp64"
+    holds that view: SURVEY 8d's per-event flop weights x IDEAL-culling event counts (counted by the device on a sample of
+    the workload's camera rays that reach the tracing kernels) x rays per launch / launch duration.  Other workloads:
+    k_visual, whose nearest hard roof is the frame record it streams per ray (56 B read + 4 B flags + 144 B per shaded
+    boundary + 56 B per queued shadow ray, + 16 B per auxiliary pair).  Durations are HIP events on the render stream
+    recorded inside the timed region and read after it.  traffic = HBM bytes per launch from PMC counters (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) of the profiles/ run named in traffic_source -- not of this run --
+    and only when this run's launches have the same size."""
     _, _, total = gs.samples(W, H, spp, 0, 0)
     ntile = total // 1600
     picks = sorted(set(int(x) for x in np.linspace(0, ntile - 1, 64)))
@@ -213,45 +301,59 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, t_trace_total, workload):
     m = len(s8)
     org, dr = gs.camera(s8[:, :2], s8[:, 2:])
     work = np.zeros(9, dtype=np.float64)
+    fast = np.zeros(2, dtype=np.float64)
     L = rt.rt_lib()
     L.rt_probe_work.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rt_probe_fast_time.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.rt_probe_fast_time(gs.h, fast.ctypes.data_as(C.POINTER(C.c_double)))
     rc = L.rt_probe_work(gs.h, m, org.ctypes.data_as(C.POINTER(C.c_double)), dr.ctypes.data_as(C.POINTER(C.c_double)), work.ctypes.data_as(C.POINTER(C.c_double)))
+    empty = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     if rc:
-        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "note": "rt_probe_work failed: %s" % L.rt_last_error().decode()}
+        return dict(empty, note="rt_probe_work failed: %s" % L.rt_last_error().decode())
     leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch, m_reach = work
-    if m_reach <= 0 or ms_per_launch <= 0:
-        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "note": "no ray reached k_visual"}
+    if m_reach <= 0:
+        return dict(empty, note="no sampled ray reached a tracing kernel")
     frac_reach = m_reach / m
-    m = m_reach         # per-ray figures are over the rays k_visual processes
+    m = m_reach         # per-ray figures are over the rays the tracing kernels process
     per_ray = (leaf * (W_AFFINE + W_QUADRIC) + boxes_ideal * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
-    flops = per_ray * rays_per_launch
-    ach = flops / (ms_per_launch * 1e-3) / 1e12
+    events = {"leaf_tests": leaf / m, "ideal_box_tests_formula_2log2K_plus_2_per_leaf": boxes_ideal / m, "merged_hits": merged / m,
+              "shaded_boundaries": boundaries / m, "light_terms": lights / m}
     d = fs.desc.contents
     area = any(d.lights[i].type == rt.RT_LIGHT_AREA for i in range(d.n_lights))
+    fast_ms, fast_launches = fast
     visual_rays = max(1, st.rays_primary + st.rays_secondary)
-    bytes_per_ray = 56.0 + (16.0 if area else 0.0) + 4.0 + 144.0 * boundaries / m + 56.0 * st.rays_shadow / visual_rays
+    if fast_launches > 0 and rays_fast_total > 0.5 * (rays_fast_total + st.rays_visual0 * steps):
+        kernel, ms_per_launch, rays_per_launch = "k_fast", fast_ms / fast_launches, rays_fast_total / fast_launches
+        bytes_per_ray = 8.0 + 12.0
+        events["box_tests_done"] = "none in this kernel: the generator tests the <= 8 boxes of the sample tile's list (k_tile_mask), no BVH walk"
+    else:
+        if ms_per_launch <= 0:
+            return dict(empty, note="no tracing kernel launch was timed")
+        kernel = "k_visual"
+        bytes_per_ray = 56.0 + (16.0 if area else 0.0) + 4.0 + 144.0 * boundaries / m + 56.0 * st.rays_shadow / visual_rays
     gbs = bytes_per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e9
-    traffic = None
+    ach = per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e12
+    traffic = source = None
     try:
         with open(TRAFFIC_FILE) as f:
             tf = json.load(f)
-        if workload.startswith(tf["workload"]):
-            traffic = tf["hbm_bytes_per_launch"]
+        if workload.startswith(tf["workload"]) and tf["kernel"] == kernel and abs(tf["rays_per_launch"] - rays_per_launch) <= 0.02 * rays_per_launch:
+            traffic, source = tf["hbm_bytes_per_launch"], tf["source"] + " (PMC passes of their own, not this run)"
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "hbm", "kernel": "k_visual", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": traffic, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch,
-            "rays_reaching_kernel": frac_reach,
+    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": source, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+            "ms_per_launch": ms_per_launch, "in_kernel_rays_per_s": rays_per_launch / (ms_per_launch * 1e-3),
+            "rays_reaching_tracing_kernels": frac_reach,
             "valu_fp64": {"achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "flops_per_ray": per_ray},
-            "events_per_ray": {"leaf_tests": leaf / m, "ideal_box_tests": boxes_ideal / m, "merged_hits": merged / m,
-                               "shaded_boundaries": boundaries / m, "light_terms": lights / m}}
+            "events_per_ray": events}
 
 
 def cpu_baseline(ge, rt, scene, name):
-    """The oracle (CPU port of the reference's algorithm, oracle/) timed on this host: a bounded sample of the
-    same workload -- the same scene and sampler at 256x144, 16 spp (same rays per sample) -- on 1 thread.
+    """The oracle (CPU port of the reference's algorithm, oracle/ -- "kind": "port": the reference itself needs Win32
+    headers and cannot be built here without stand-ins) timed on this host: a bounded sample of the same workload -- the
+    same scene and sampler at 512x288, 16 spp (same rays per sample) -- first on 1 thread (the reference is single-threaded),
+    then on the box's share of host cores (OpenMP over samples; results do not depend on the thread count).
     For the mesh workloads the oracle tests every triangle per ray (the reference has no hierarchy over triangles
     either: ObjectFormat.cpp holds flat arrays), so the sample is a few hundred rays."""
     ob = ge.load_oracle()
@@ -262,14 +364,21 @@ def cpu_baseline(ge, rt, scene, name):
     w, h, spp = (512, 288, 16) if name == "S0" else (640, 360, 16)     # about 15-25 s of single-thread work
     if name.startswith("MESH"):
         w, h, spp = {"MESH10M": (12, 8, 1), "MESH1M": (40, 24, 1)}.get(name, (128, 72, 1))
-    scene = name
-    rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
-    st = rt.RtStats()
-    t0 = time.perf_counter()
-    osc.render(w, h, spp, rd, st, threads=1)
-    dt = time.perf_counter() - t0
-    return {"value": st.rays() / dt, "unit": "rays/s", "cores": 1, "kind": "port",
-            "sample": "%s %dx%d %d spp %s, %d rays in %.1f s, single thread (the reference is single-threaded)" % (scene, w, h, spp, "FastBlue" if sampler == "fastblue" else "one ray per pixel", st.rays(), dt)}
+    if name.startswith("S4"):
+        w, h, spp = 160, 90, 4
+    out = []
+    cores = min(16, len(os.sched_getaffinity(0)))       # the GPU box gives a one-GPU job 16 host cores
+    for threads in (1, cores):
+        rd = rt.RtRenderDesc(w, h, float(spp), 0, 0)
+        st = rt.RtStats()
+        t0 = time.perf_counter()
+        osc.render(w, h, spp, rd, st, threads=threads)
+        dt = time.perf_counter() - t0
+        out.append({"value": st.rays() / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+                    "sample": "%s %dx%d %d spp %s, %d rays in %.1f s on %d thread%s (oracle/, the CPU restatement of the reference; the reference itself is single-threaded)"
+                              % (name, w, h, spp, "FastBlue" if sampler == "fastblue" else "one ray per pixel", st.rays(), dt, threads, "" if threads == 1 else "s")})
+        note("cpu baseline on %d thread(s) done" % threads)
+    return out[0], out[1]
 
 
 if __name__ == "__main__":

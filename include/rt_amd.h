@@ -122,6 +122,11 @@ void rt_random_skip(uint32_t state_xc[2], uint64_t ndraws);
    k_visual.  out9: 9 doubles. */
 int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, double *out9);
 
+/* Measurement support for bench.py (no counterpart in the reference): out2[0] = total duration in ms (HIP events on the
+   render stream) and out2[1] = number of the k_fast launches made since the previous call while option "time_kernels" was 1.
+   k_fast traces the primary rays that can only touch bare chains of the root union region (RtStats.rays_fast of them). */
+int  rt_probe_fast_time(rt_scene *s, double *out2);
+
 /* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 33,552,000 = 20970 sampling tiles; the queues of a pass take about 2 KB of HBM per sample),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
    "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
@@ -147,7 +152,12 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    multiple of 1600; results do not depend on it),
    "full_tables" (0/1, default 1: those kernels also read chain records and scene tables from LDS when two of their
    workgroups fit a CU; at rt_scene_upload),
-   "time_kernels" (0/1: HIP events around the k_visual launches, read back by rt_probe_work). */
+   "time_kernels" (0/1: HIP events around the k_visual and k_fast launches, read back by rt_probe_work / rt_probe_fast_time),
+   "fast_path" (0/1, default 1: primary rays that can only touch bare chains of the root union region -- two-root primitives
+   without texture call-outs, propagators or spectral metals -- are traced by k_fast: no interpreter, no hit arena, hits in
+   registers, and no frame where neither a shadow ray nor a child ray is needed; at rt_scene_upload; results do not depend on it),
+   "level_sync" (0/1, default 0: 1 makes every pass wait for the host after every level, also where the device-side
+   bounds make that unnecessary; for A/B runs). */
 int  rt_set_option(const char *name, int64_t value);
 /* the current value of a tunable, -1 (and rt_last_error) for an unknown name */
 int64_t rt_get_option(const char *name);

@@ -109,3 +109,55 @@ def gather_bands(planes, bands, rank, world, dist):
         for r in range(world):
             planes[:, bands[r]:bands[r + 1], :] = out[r][:, : bands[r + 1] - bands[r], :].to(planes.device)
     return planes
+
+
+# ---- frame-parallel animation ("S4: frame-parallel across ranks first") ----------------------------
+
+def laboratory_times():
+    """The frame times of Laboratory()'s loop, `for (t = 3.0; t <= 6.0; t += 3.0/120.0)` (LaboratoryAnimation.cpp:410):
+    accumulated in double exactly as the reference accumulates them."""
+    out, t = [], 3.0
+    while t <= 6.0:
+        out.append(t)
+        t += 3.0 / 120.0
+    return out
+
+
+def frame_assignment(n_frames, world):
+    """Which frames each rank renders: frame i goes to rank i % world (whole frames, no exchange while rendering; the
+    finished frames are what rank 0 collects).  With fewer frames than ranks the surplus ranks get none -- such a job is
+    better split by rows (row_bands)."""
+    return [list(range(r, n_frames, world)) for r in range(world)]
+
+
+def gather_frames(frames, owner_of, rank, world, dist):
+    """Collect whole frames on rank 0.  frames: {frame index: tensor [3][H][W]} rendered by this rank; owner_of: frame
+    index -> rank, for every frame of the batch.  One torch.distributed.gather per round of `world` frames (RCCL on
+    GPUs, gloo on CPU): in round k every rank that has a k-th frame sends it.  Returns {index: tensor} on rank 0."""
+    import torch
+    if world == 1:
+        return dict(frames)
+    per_rank = [[i for i in sorted(owner_of) if owner_of[i] == r] for r in range(world)]
+    rounds = max(len(p) for p in per_rank)
+    like = next(iter(frames.values())) if frames else None
+    shape = [None]
+    if rank == 0:
+        shape[0] = tuple(like.shape) if like is not None else None
+    dist.broadcast_object_list(shape, src=0)
+    out_all = {}
+    for k in range(rounds):
+        mine = per_rank[rank][k] if k < len(per_rank[rank]) else None
+        if mine is not None:
+            slab = frames[mine]
+        else:
+            dev = like.device if like is not None else "cpu"
+            slab = torch.zeros(shape[0], dtype=torch.float32, device=dev)
+        if slab.is_cuda and dist.get_backend() == "gloo":
+            slab = slab.cpu()
+        out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+        dist.gather(slab.contiguous(), out, dst=0)
+        if rank == 0:
+            for r in range(world):
+                if k < len(per_rank[r]):
+                    out_all[per_rank[r][k]] = out[r]
+    return out_all

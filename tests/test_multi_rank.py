@@ -63,6 +63,54 @@ def test_band_gather_gloo(world, height):
     assert q.get(timeout=5) is True
 
 
+def _frames_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_frames = 5
+        assign = rt.sharding.frame_assignment(n_frames, world)
+        owner = {i: r for r in range(world) for i in assign[r]}
+        # every frame is a constant image of its own index: what arrives where is all that is tested
+        mine = {i: torch.full((3, 4, 6), float(i + 1)) for i in assign[rank]}
+        got = rt.sharding.gather_frames(mine, owner, rank, world, dist)
+        if rank == 0:
+            q.put(sorted(got) == list(range(n_frames)) and all(bool((got[i] == float(i + 1)).all()) for i in got))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_parallel_gather_gloo(world):
+    """Frame-parallel animation (Laboratory()'s loop, LaboratoryAnimation.cpp:410-436): whole frames are dealt round robin
+    to the ranks, nothing is exchanged while rendering, rank 0 collects the finished frames."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + world * 11 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_laboratory_frame_times_and_assignment():
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    ts = rt.sharding.laboratory_times()
+    assert ts[0] == 3.0 and ts[1] == 3.0 + 3.0 / 120.0 and ts[-1] <= 6.0 < ts[-1] + 3.0 / 120.0 and len(ts) in (120, 121)
+    for n, w in ((121, 8), (5, 2), (3, 8), (0, 4)):
+        a = rt.sharding.frame_assignment(n, w)
+        assert len(a) == w and sorted(i for r in a for i in r) == list(range(n))
+        assert max(len(r) for r in a) - min(len(r) for r in a) <= 1
+
+
 def test_row_bands_partition():
     import __graft_entry__ as ge
     rt = ge.load_package()
