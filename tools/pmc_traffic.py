@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over one frame of a bench.py workload.
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> <bench.json of the same workload> <kernel> <source label> <out.json> [<out.txt>]
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B for every 128-B request of a wide streaming read
+(MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is exact for streaming stores.  Both were checked on
+kernels of this library whose byte counts are known (k_resample_rows reads the 8.49 GB supersampled image,
+k_splat_gather writes it)."""
+import collections, csv, glob, json, sys
+
+
+def sums(d):
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+fd, wd, bench, kernel, source, out = sys.argv[1:7]
+fetch, nf = sums(fd)
+write, nw = sums(wd)
+b = json.loads(open(bench).read().strip().splitlines()[-1])
+lines = ["%-34s %8s %16s %16s %16s" % ("kernel", "launches", "read B (2xFETCH)", "written B", "HBM B / launch")]
+for k in sorted(set(fetch) | set(write)):
+    n = max(nf.get(k, 0), nw.get(k, 0), 1)
+    rd, wr = 2.0 * 1024.0 * fetch.get(k, 0.0), 1024.0 * write.get(k, 0.0)
+    lines.append("%-34s %8d %16.0f %16.0f %16.0f" % (k[:34], n, rd, wr, (rd + wr) / n))
+txt = "\n".join(lines)
+print(txt)
+if len(sys.argv) > 7:
+    open(sys.argv[7], "w").write(txt + "\n")
+key = [k for k in fetch if k.startswith(kernel)]
+if key:
+    k = key[0]
+    n = max(nf[k], nw.get(k, 0), 1)
+    rd, wr = 2.0 * 1024.0 * fetch[k], 1024.0 * write.get(k, 0.0)
+    r = b["roofline"]
+    json.dump({"workload": b["config"]["workload"].split(" (")[0], "kernel": kernel, "launches_per_frame": n,
+               "rays_per_launch": r["rays_per_launch"], "hbm_bytes_read_per_launch": rd / n, "hbm_bytes_written_per_launch": wr / n,
+               "hbm_bytes_per_launch": (rd + wr) / n, "hbm_bytes_per_ray": (rd + wr) / n / r["rays_per_launch"],
+               "algorithmic_bytes_per_ray": r["bytes_per_ray"], "source": source}, open(out, "w"), indent=1)
