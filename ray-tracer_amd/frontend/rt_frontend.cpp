@@ -492,6 +492,70 @@ Solid *Slaboid(double x, double y, double z, double r)
         new Translate(-x + r, +y - r, 0.0, new Scale(r, r, z, new Cylinder)),
         new Translate(-x + r, -y + r, 0.0, new Scale(r, r, z, new Cylinder))));
 }
+/* Solids.cpp:2011-2049: a box with two rounding radii -- r for the four upright edges, r2 for the rims of the two faces.
+   Three groups in the reference's child order: plates and corner posts, eight corner rounds, eight rim rods. */
+Solid *Slaboidoid(double x, double y, double z, double r, double r2)
+{
+    const double f90 = 90.0 * D_PI / 180.0, rc = r - r2;
+    static const int sgn[4][2] = { { +1, +1 }, { +1, -1 }, { -1, +1 }, { -1, -1 } };
+    Solid *core[8], *corner[8], *rim[8];
+    core[0] = new Scale(x - r, y, z - r2, new Cube);
+    core[1] = new Scale(x, y - r, z - r2, new Cube);
+    core[2] = new Scale(x - r, y - r2, z, new Cube);
+    core[3] = new Scale(x - r2, y - r, z, new Cube);
+    for (int k = 0; k < 4; k++)
+        core[4 + k] = new Translate(sgn[k][0] * (x - r), sgn[k][1] * (y - r), 0.0, new Scale(r, r, z - r2, new Cylinder));
+    for (int k = 0; k < 8; k++) {
+        double sx = (k & 4) ? -1.0 : 1.0, sy = (k & 2) ? -1.0 : 1.0, sz = (k & 1) ? -1.0 : 1.0;
+        corner[k] = new Translate(sx * (x - r), sy * (y - r), sz * (z - r2), new Scale(rc, rc, rc, Diskoid(r2 / rc)));
+    }
+    for (int k = 0; k < 4; k++) {
+        rim[k] = new Translate(sgn[k][0] * (x - r2), 0.0, sgn[k][1] * (z - r2), new Scale(r2, y - r, r2, new Rotate(f90, 0.0, 0.0, new Cylinder)));
+        rim[4 + k] = new Translate(0.0, sgn[k][0] * (y - r2), sgn[k][1] * (z - r2), new Scale(x - r, r2, r2, new Rotate(0.0, f90, 0.0, new Cylinder)));
+    }
+    return new BoundingBox(MakeUnion(rt_make_union(core, 8, 0), rt_make_union(corner, 8, 0), rt_make_union(rim, 8, 0)));
+}
+
+/* Solids.cpp:2173-2230: text out of cylinders and spheres, one boxed union per glyph, 12 font units per character cell and
+   per unit of length.  The glyphs (Solids.cpp:2062-2171) are data: table "rgFont" of tables.bin, 8 codes per glyph --
+   x in the high nibble, y in the low one, 0xFE lifts the pen, 0xFF ends the glyph.  Lower case is drawn as small capitals. */
+Solid *SolidText(double xStart, double yStart, const char *sz, int nJust, double r)
+{
+    int dt = 0, cnt = 0;
+    const int *font = (const int *)rt_table_find("rgFont", &dt, &cnt);
+    if (!font || dt != RT_TABLE_I32 || cnt % 8) { fprintf(stderr, "rt_frontend: missing table rgFont\n"); abort(); }
+    const int nGlyphs = cnt / 8;
+    double xJust = 0.0;
+    if (nJust == JUSTIFIED_RIGHT) xJust = -12.0 * strlen(sz);
+    else if (nJust != JUSTIFIED_LEFT) xJust = -12.0 * strlen(sz) / 2.0;
+    Solid *text = 0;
+    for (int i = 0; sz[i]; i++) {
+        const double xOrg = xStart + 12 * i + xJust, yOrg = yStart;
+        double xPen = xOrg, yPen = yOrg;
+        int glyph = (unsigned char)sz[i] - ' ';
+        if (glyph < 0 || glyph >= nGlyphs) glyph = 0;
+        const bool small = sz[i] >= 'a' && sz[i] <= 'z';
+        bool down = false;
+        Solid *letter = 0;
+        for (int j = 0; j < 8; j++) {
+            int code = font[8 * glyph + j];
+            if (code == 0xFF) break;
+            if (code == 0xFE) { down = false; continue; }
+            double dx = (code >> 4) & 15, dy = code & 15;
+            if (small) dy *= 0.75;
+            if (down) {
+                Point3 from(xPen / 12.0, -yPen / 12.0, 0.0), to((xOrg + dx) / 12.0, -(yOrg + dy) / 12.0, 0.0);
+                letter = MakeUnion(letter, CylinderFromTo(from, to, r), (Solid *)new Translate(to, new Scale(r, r, r, new Sphere)));
+            }
+            xPen = xOrg + dx;
+            yPen = yOrg + dy;
+            letter = MakeUnion(letter, (Solid *)new Translate(xPen / 12.0, -yPen / 12.0, 0.0, new Scale(r, r, r, new Sphere)));
+            down = true;
+        }
+        if (letter) text = MakeUnion(text, (Solid *)new BoundingBox(letter));
+    }
+    return new BoundingBox(text ? text : new NullSolid);
+}
 
 /* --------------------------------------------------------- texture / propagator identities ---- */
 static volatile int s_texfn_tag;

@@ -471,6 +471,21 @@ Solid *Knoboid(double r, double z = 1.0);
 Solid *Knoboid2(double r, double z = 1.0);
 Solid *Hyperboloidoid(double r, double rt, double z = 1.0);
 Solid *Slaboid(double x, double y, double z, double r);
+Solid *Slaboidoid(double x, double y, double z, double r, double r2);
+#define JUSTIFIED_RIGHT  0                      /* Image.h:30-32 */
+#define JUSTIFIED_LEFT   1
+#define JUSTIFIED_CENTER 2
+Solid *SolidText(double xStart, double yStart, const char *sz, int nJust, double r);    /* Solids.cpp:2173-2230 */
+#define DENSE_AIR       0.000293                /* Solids.h:226-234 */
+#define DENSE_VENUS     0.014716
+#define DENSE_WATER     0.333
+#define DENSE_ICE       0.36
+#define DENSE_PYREX     0.474
+#define DENSE_GLASS     0.52
+#define DENSE_LEADGLASS 0.71
+#define DENSE_SAPPHIRE  0.77
+#define DENSE_DIAMOND   1.42
+#define DODECDIHEDRAL   116.56505117707798935157219372045
 
 /* --------------------------------------------------- lights (RayTracer2020.h:143-172, Lights.h) ---- */
 struct Light {

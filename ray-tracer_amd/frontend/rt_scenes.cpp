@@ -592,6 +592,8 @@ struct Parser {
 };
 }
 
+int rt_build_conformance_scene(const char *spec, RayTracer &rt, std::string *err);     /* rt_scenes_conformance.cpp */
+
 /* ------------------------------------------------------------------------ C entry points ---- */
 struct rtf_scene {
     RayTracer   rt;
@@ -601,7 +603,7 @@ static char s_scene_err[512];
 
 extern "C" const char *rtf_last_error() { return s_scene_err[0] ? s_scene_err : rt_frontend_last_error(); }
 
-/* spec: "S0" | "S1" | "S2" | "S4" | "S4@t" | "(scene ...)".  sampler: "", "test", "jitter" or "fastblue" overrides the scene's tile.
+/* spec: "S0" | "S1" | "S2" | "S4" | "S4@t" | a conformance scene name (rt_scenes_conformance.cpp) | "(scene ...)".  sampler: "", "test", "jitter" or "fastblue" overrides the scene's tile.
    optimize != 0 calls psModel->Optimize() before flattening (what every reference driver does). */
 extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int optimize)
 {
@@ -615,6 +617,12 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     else if (name == "S2") rc = build_S2(s->rt);
     else if (name == "S4") rc = build_S4(s->rt, 4.5);
     else if (name.compare(0, 3, "S4@") == 0) rc = build_S4(s->rt, atof(name.c_str() + 3));
+    else if (name[0] != '(') {
+        std::string why;
+        int k = rt_build_conformance_scene(spec, s->rt, &why);
+        if (k == 0) why = "unknown scene name " + name;
+        if (k <= 0) { snprintf(s_scene_err, sizeof s_scene_err, "%s", why.c_str()); delete s; return 0; }
+    }
     else {
         reset_globals();
         Parser ps(spec, &s->rt);

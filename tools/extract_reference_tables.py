@@ -88,6 +88,27 @@ def main():
     for m in re.finditer(r"(g_rgb\w+)\(\s*([-+0-9.eE]+)\s*,\s*([-+0-9.eE]+)\s*,\s*([-+0-9.eE]+)\s*\)", rc):
         tables[m.group(1)] = np.array([np.float32(float(m.group(i))) for i in (2, 3, 4)], dtype=np.float32)
 
+    # Solids.cpp: the vector font of SolidText, rgFont[ML_NFONT] = up to 8 pen positions per glyph as one byte each
+    # (x in the high nibble, y in the low one; 0xFE lifts the pen, 0xFF ends the glyph; short rows are zero-filled by C)
+    so = read("Solids.cpp")
+    m = re.search(r"VectorFont\s+rgFont\s*\[\s*ML_NFONT\s*\]\s*=\s*\{(.*?)\n\};", so, re.S)
+    assert m, "rgFont"
+    glyphs = []
+    for row in re.findall(r"\{([^{}]*)\}", m.group(1)):
+        codes = []
+        for tok in re.findall(r"P\(\s*\d+\s*,\s*\d+\s*\)|FONT_UP|FONT_LAST", row):
+            if tok == "FONT_UP":
+                codes.append(0xFE)
+            elif tok == "FONT_LAST":
+                codes.append(0xFF)
+            else:
+                x, y = [int(v) for v in re.findall(r"\d+", tok)]
+                codes.append(((x & 15) << 4) | (y & 15))
+        assert 1 <= len(codes) <= 8, row
+        glyphs.append(codes + [0] * (8 - len(codes)))
+    assert len(glyphs) == 95 + 11, len(glyphs)
+    tables["rgFont"] = np.array(glyphs, dtype=np.int32).reshape(-1)
+
     # ---- write tables.bin: magic, n, directory {name[40], dtype u32, count u32, offset u64}, payload (8B aligned)
     names = sorted(tables)
     DT = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2}
