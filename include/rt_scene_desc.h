@@ -64,7 +64,7 @@ enum RtTextureId {
     RT_TEX_VEINS = 22, RT_TEX_SEASCAPE = 23, RT_TEX__COUNT
 };
 /* Propagator function pointers (Solids.h:267); 0 = none. */
-enum RtPropagatorId { RT_PROP_NONE = 0, RT_PROP_COLOREDGLASS = 1, RT_PROP_FOGGY = 2, RT_PROP__COUNT };
+enum RtPropagatorId { RT_PROP_NONE = 0, RT_PROP_COLOREDGLASS = 1, RT_PROP_FOGGY = 2, RT_PROP_ATMOSPHERE = 3, RT_PROP__COUNT };
 
 typedef struct RtNode {
     int32_t type;       /* RtNodeType */

@@ -232,9 +232,31 @@ void transform_normals_export(Hit &h, const Ctx &cx) { transform_normals(h, cx);
 struct Prop { Spec tr, ster; };
 
 /* TextureMaps.cpp:13-57 */
-static Prop propagate(int id, const V3 &p0, const V3 &p1, const Node *pm)
+static Prop propagate(const Scene &s, int id, const V3 &p0, const V3 &p1, const Node *pm)
 {
     Prop p;
+    if (id == RT_PROP_ATMOSPHERE) {
+        /* NEW BEHAVIOUR (the reference's Atmosphere is an empty stub, TextureMaps.cpp:162-168): Rayleigh extinction with the
+           constants of Rayleigh() (:123-135) -- K = 1e36 * 1e3 * 24 pi^3 * ((n^2-1)/(n^2+2))^2 / N over the wavelength in nm to
+           the fourth, per kilometre; N from n = sqrt(1 + alpha N) (:117-121) with POLARIZABILITY_AIR (:107); the material's
+           colour scales the coefficient per band; scene units are metres -- and airlight (1 - T) times the ambient radiance. */
+        const double n2 = pm->refr * pm->refr;
+        double K = 0.0;
+        if (n2 > 1.0) {
+            const double ll = (n2 - 1.0) / (n2 + 2.0), N = (n2 - 1.0) / 2.133e-29;
+            K = 1.0e36 * 1.0e3 * (24.0 * kPi * kPi * kPi) * (ll * ll) / N;
+        }
+        const double km = norm(p1 - p0) / 1000.0;
+        for (int i = 0; i < NSPEC; i++) {
+            const double lam = 380.0 + 40.0 * i, l2 = lam * lam;
+            double x = (double)pm->color.v[i] * K / (l2 * l2) * km, T;
+            if (x > 87.0) T = 0.0; else T = exp(-x);
+            p.tr.v[i] = float(T);
+            float a = float(1.0 - T);
+            p.ster.v[i] = s.has_ambient ? float(double(a) * double(s.ambient.v[i])) : 0.0f;
+        }
+        return p;
+    }
     if (id == RT_PROP_FOGGY) {
         double t = norm(p1 - p0);
         for (int i = 0; i < NSPEC; i++) {
@@ -284,7 +306,7 @@ Spec light_ray(Scene &s, const Ray &ray, const Light &l, Ctx &cx)
         if (pm->i0 != RT_MAT_TRANSPARENT || h.mat->i0 != RT_MAT_TRANSPARENT || roughness(h) != RT_SURF_POLISHED)
             return black;
         if (pm->i2) {
-            Prop p = propagate(pm->i2, at(ray, t), at(ray, h.t), pm);
+            Prop p = propagate(s, pm->i2, at(ray, t), at(ray, h.t), pm);
             tr = tr * p.tr;
         }
         if (pm->refr != h.mat->refr) {
@@ -300,7 +322,7 @@ Spec light_ray(Scene &s, const Ray &ray, const Light &l, Ctx &cx)
         pm = h.mat;
     }
     if (pm->i2 && pm->i0 == RT_MAT_TRANSPARENT) {
-        Prop p = propagate(pm->i2, at(ray, t), at(ray, 1.0), pm);
+        Prop p = propagate(s, pm->i2, at(ray, t), at(ray, 1.0), pm);
         tr = tr * p.tr;
     }
     return E * tr;
@@ -353,7 +375,7 @@ Spec visual_ray(Scene &s, const Ray &ray, Ctx &cx)
             return pm->color;
         }
         if (pm->i2) {
-            Prop p = propagate(pm->i2, at(ray, t), at(ray, h.t), pm);
+            Prop p = propagate(s, pm->i2, at(ray, t), at(ray, h.t), pm);
             tr = tr * p.tr;
             R = R + p.ster;
         }
@@ -409,7 +431,7 @@ Spec visual_ray(Scene &s, const Ray &ray, Ctx &cx)
         }
     }
     if (pm->i2) {
-        Prop p = propagate(pm->i2, at(ray, t), at(ray, kInf), pm);
+        Prop p = propagate(s, pm->i2, at(ray, t), at(ray, kInf), pm);
         R = R + tr * p.ster;
         tr = tr * p.tr;
     }

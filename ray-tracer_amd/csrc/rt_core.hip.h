@@ -1813,9 +1813,30 @@ RT_DEV Spec ray_reflectance(int luster, const Spec &color, double F)
     return spec_const(0.0f);
 }
 
-/* ColoredGlass / Foggy, TextureMaps.cpp:13-57 */
-RT_DEVN void propagate(int id, const D3 &p0, const D3 &p1, const float *color, Spec &tr, Spec &ster)
+/* ColoredGlass / Foggy, TextureMaps.cpp:13-57; Atmosphere: the slot the reference leaves empty (TextureMaps.cpp:162-168),
+   filled with Rayleigh extinction and ambient airlight -- DESIGN.md 7b, "Atmosphere" */
+RT_DEVN void propagate(int id, const D3 &p0, const D3 &p1, const float *color, double refr, Spec &tr, Spec &ster)
 {
+    if (id == RT_PROP_ATMOSPHERE) {
+        /* Rayleigh() (TextureMaps.cpp:123-135): K = 1e36 * 1e3 * 24 pi^3 * ((n^2-1)/(n^2+2))^2 / N, divided by the wavelength in
+           nanometres to the fourth = scattering coefficient per kilometre; number density N from n = sqrt(1 + alpha N)
+           (RefractiveIndex, :117-121) with POLARIZABILITY_AIR (:107).  Scene units are metres, as in ColoredGlass. */
+        const double n2 = refr * refr;
+        double K = 0.0;
+        if (n2 > 1.0) {
+            const double ll = (n2 - 1.0) / (n2 + 2.0), N = (n2 - 1.0) / 2.133e-29;
+            K = 1.0e36 * 1.0e3 * (24.0 * RT_PI * RT_PI * RT_PI) * (ll * ll) / N;
+        }
+        const double km = norm(p1 - p0) / 1000.0;
+        for (int i = 0; i < RT_NSPEC; i++) {
+            const double lam = 380.0 + 40.0 * i, l2 = lam * lam;
+            double x = (double)color[i] * K / (l2 * l2) * km, T;
+            if (x > 87.0) T = 0.0; else T = exp(-x);
+            tr.v[i] = (float)T;
+            ster.v[i] = (float)(1.0 - T);       /* times the ambient radiance: propagate_in() below */
+        }
+        return;
+    }
     if (id == RT_PROP_FOGGY) {
         double t = norm(p1 - p0);
         for (int i = 0; i < RT_NSPEC; i++) {
@@ -1832,6 +1853,18 @@ RT_DEVN void propagate(int id, const D3 &p0, const D3 &p1, const float *color, S
         double mu = (double)color[i] * t, T;
         if (mu > 87.0) T = 0.0; else T = exp(-mu);
         tr.v[i] = (float)T;
+    }
+}
+
+/* the propagator call of Shade.cpp:333-336, :438-442, :512-516; `scene` is what the slot's RayTracer* argument gives access to:
+   Atmosphere scatters the scene's ambient radiance into the path (flux of plAmbient; black without one) */
+template <class SCENE>
+RT_DEV void propagate_in(const SCENE &S, int id, const D3 &p0, const D3 &p1, const float *color, double refr, Spec &tr, Spec &ster)
+{
+    propagate(id, p0, p1, color, refr, tr, ster);
+    if (id == RT_PROP_ATMOSPHERE) {
+#pragma unroll
+        for (int i = 0; i < RT_NSPEC; i++) ster.v[i] = S.has_ambient ? (float)((double)ster.v[i] * (double)S.ambient[i]) : 0.0f;
     }
 }
 

@@ -620,7 +620,7 @@ RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux,
             if constexpr (LITE) { bail = true; break; }
             else {
                 Spec ptr, pst;
-                propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
+                propagate_in(S, mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, mp.refr, ptr, pst);
                 tr = tr * ptr;
                 R = R + pst;
                 B.r_state = 2; B.tr_one = false;
@@ -681,7 +681,7 @@ RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux,
         if constexpr (LITE) bail = true;
         else {
             Spec ptr, pst;
-            propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
+            propagate_in(S, S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, S.mats[pm].refr, ptr, pst);
             K.fin(tr * pst);
             B.flags |= FR_FIN;
         }
@@ -832,7 +832,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                 if constexpr (LITE) { bail = true; break; }
                 else {
                     Spec ptr, pst;
-                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
+                    propagate_in(S, mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, mp.refr, ptr, pst);
                     tr = tr * ptr;
                     R = R + pst;
                     r_state = 2; tr_one = false;
@@ -902,7 +902,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
             if constexpr (LITE) bail = true;
             else {
                 Spec ptr, pst;
-                propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
+                propagate_in(S, S.mats[pm].prop, ray_at(ray, t), ray_at(ray, RT_INFINITY), pm_has_color ? pm_color.v : S.mats[pm].color, S.mats[pm].refr, ptr, pst);
                 spec_store(P.f_fin, P.fcap, f, tr * pst);
                 flags |= FR_FIN;
             }
@@ -1213,7 +1213,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
                 if constexpr (LITE) { bail = true; break; }
                 else {
                     Spec ptr, pst;
-                    propagate(mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, ptr, pst);
+                    propagate_in(S, mp.prop, ray_at(ray, t), ray_at(ray, h.t), mp_colorp, mp.refr, ptr, pst);
                     tr = tr * ptr;
                 }
             }
@@ -1237,7 +1237,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
                     if constexpr (LITE) bail = true;
                     else {
                         Spec ptr, pst;
-                        propagate(S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), pm_has_color ? pm_color.v : S.mats[pm].color, ptr, pst);
+                        propagate_in(S, S.mats[pm].prop, ray_at(ray, t), ray_at(ray, 1.0), pm_has_color ? pm_color.v : S.mats[pm].color, S.mats[pm].refr, ptr, pst);
                         tr = tr * ptr;
                     }
                 }

@@ -566,6 +566,8 @@ TEXFN(VoronoiBump) TEXFN(VoronoiAntiBump) TEXFN(VoronoiCrinkled)
 TEXFN(Voronoi) TEXFN(Agate) TEXFN(Marble) TEXFN(Clouds) TEXFN(Wood) TEXFN(Spots) TEXFN(Veins) TEXFN(SeaScape)
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
+/* TextureMaps.cpp:162-168 is an empty stub; here the name selects the device's Rayleigh propagator */
+Propagation Atmosphere(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 int rt_texture_id(TextureMap f)
 {
     if (!f) return RT_TEX_NONE;
@@ -584,6 +586,7 @@ int rt_propagator_id(Propagator f)
     if (!f) return RT_PROP_NONE;
     if (f == ColoredGlass) return RT_PROP_COLOREDGLASS;
     if (f == Foggy) return RT_PROP_FOGGY;
+    if (f == Atmosphere) return RT_PROP_ATMOSPHERE;
     return -1;
 }
 

@@ -367,6 +367,7 @@ void Veins(const Point3 &, Hit *, RayTracer *);
 void SeaScape(const Point3 &, Hit *, RayTracer *);
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *);
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *);
+Propagation Atmosphere(const Point3 &, const Point3 &, Material *, RayTracer *);
 int rt_texture_id(TextureMap f);        /* -1: not a device routine */
 int rt_propagator_id(Propagator f);
 

@@ -16,7 +16,7 @@
  *       five-neck Florence flask on a copper stand, an Erlenmeyer flask, a condenser envelope of length t with a
  *       spiral tube inside, all Pyrex; floor and sky dome of Environment (:368-385); HavercosineLight ambient, one
  *       point light, StereographicCamera((0,0,12)).  "S4" is the frame t = 4.5; "S4@t" any t of the animation
- *       (3 <= t <= 6 there).
+ *       (3 <= t <= 6 there).  "S4atm" / "S4atm@t": the same frame in hazy air (the Atmosphere propagator).
  * Argument evaluation order where the reference leaves it to the compiler (RandomDouble() calls
  * as constructor arguments): right to left, which is what both MSVC and g++ do.
  */
@@ -326,7 +326,11 @@ Solid *Environment(Solid *ps)                       /* :368-385 */
 }
 }   // namespace lab
 
-static int build_S4(RayTracer &rt, double t)        /* Laboratory(), LaboratoryAnimation.cpp:387-442, the frame at time t */
+/* Laboratory(), LaboratoryAnimation.cpp:387-442, the frame at time t.  haze: the room filled with air whose Rayleigh
+   coefficient is scaled a thousandfold (BASELINE configs[4] "with Atmosphere scattering"; the reference's Atmosphere is a
+   stub, so this is documented new behaviour in the Propagator slot -- DESIGN.md 7b): a sphere of air larger than the
+   sky dome, so no ray ever meets its boundary. */
+static int build_S4(RayTracer &rt, double t, bool haze = false)
 {
     using namespace lab;
     reset_globals();
@@ -348,6 +352,8 @@ static int build_S4(RayTracer &rt, double t)        /* Laboratory(), LaboratoryA
         Glass(new Translate(+0.0, 0.5 * t, -0.5, new Rotate(0.0, -30.0 * D_PI / 180.0, 0.0, CondensorEnvelope(t)))),
         Glass(new Translate(+0.0, 0.5 * t, -0.5, SpiralTube(t))));
     rt.psModel = Environment(ps);
+    if (haze)
+        rt.psModel = new Union(rt.psModel, new Scale(150.0, 150.0, 150.0, new Material(DENSE_AIR, REFRACT_AIR, g_sEqualWhite * 1000.0, MAT_TRANSPARENT, Atmosphere, new Sphere)));
     return 0;
 }
 
@@ -433,6 +439,7 @@ struct Parser {
         if (w == "none") return 0;
         if (w == "coloredglass") return ColoredGlass;
         if (w == "foggy") return Foggy;
+        if (w == "atmosphere") return Atmosphere;
         fail("unknown propagator " + w);
         return 0;
     }
@@ -617,6 +624,8 @@ extern "C" rtf_scene *rtf_scene_build(const char *spec, const char *sampler, int
     else if (name == "S2") rc = build_S2(s->rt);
     else if (name == "S4") rc = build_S4(s->rt, 4.5);
     else if (name.compare(0, 3, "S4@") == 0) rc = build_S4(s->rt, atof(name.c_str() + 3));
+    else if (name == "S4atm") rc = build_S4(s->rt, 4.5, true);
+    else if (name.compare(0, 6, "S4atm@") == 0) rc = build_S4(s->rt, atof(name.c_str() + 6), true);
     else if (name[0] != '(') {
         std::string why;
         int k = rt_build_conformance_scene(spec, s->rt, &why);

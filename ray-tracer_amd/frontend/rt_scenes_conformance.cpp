@@ -17,6 +17,7 @@
  *   Venera[@t 0]         Venera() frame t (Venera.cpp:144-670): the lander (landing ring with flanges and bolts, hull,
  *                        struts, two cameras, colour chips) in EnvironmentLab
  *   VeneraVenus[@t 0]    the same lander in EnvironmentVenus (:237-259)
+ *   VeneraAtmosphere[@t] VeneraVenus under Venus's air: the Atmosphere propagator (new behaviour, not a reference scene)
  *   Megacycles[@t 0]     Megacycles() frame t (Megacycles.cpp:8-349): 189 robot unicyclists on a second-order Peano curve
  *   Unicyclist[@t 0]     one rider of that scene, close up
  * Lights and cameras: the drivers' own where a driver exists (Venera, Megacycles, Lorenz); the TestScene models get
@@ -722,6 +723,12 @@ Solid *OnVenus(Solid *ps, RayTracer &rt)        /* EnvironmentVenus, :237-259 */
     ps = join(ps, size(1000.0, mat(0.9, sky * 1.5, MAT_NOSHADE, new HollowSphere)));
     return turn(-rad(10.0), 0.0, 0.0, ps);
 }
+/* not in the reference: the Venus of OnVenus under its own air -- refractive index of the surface atmosphere (VENUS_REFRACT,
+   TextureMaps.cpp:99) in the Atmosphere propagator, a sphere larger than the sky dome so no ray meets its boundary */
+Solid *UnderVenusAir(Solid *ps)
+{
+    return join(ps, size(1500.0, mat(DENSE_VENUS, 1.014716, g_sEqualWhite, MAT_TRANSPARENT, Atmosphere, new Sphere)));
+}
 }   // namespace venera
 
 /* --------------------------------------------------------------------------------------------- Megacycles.cpp ---- */
@@ -875,7 +882,7 @@ int rt_build_conformance_scene(const char *spec, RayTracer &rt, std::string *err
     int which = -1;
     for (size_t k = 0; k < sizeof models / sizeof models[0]; k++) if (name == models[k].n) which = (int)k;
     const bool extra = name == "Model6" || name == "ModelD" || name == "ModelG" || name == "ModelK" || name == "ModelS" || name == "Ruby" || name == "Fib" || name == "Lorenz";
-    const bool driver = name == "Venera" || name == "VeneraVenus" || name == "Megacycles" || name == "Unicyclist";
+    const bool driver = name == "Venera" || name == "VeneraVenus" || name == "VeneraAtmosphere" || name == "Megacycles" || name == "Unicyclist";
     if (which < 0 && !extra && !driver) return 0;
 
     /* every scene starts from the default PRNG seeds and auxiliary dimensions */
@@ -883,11 +890,12 @@ int rt_build_conformance_scene(const char *spec, RayTracer &rt, std::string *err
     g_uCamera = g_vCamera = g_uLight = g_vLight = g_uMicroFacet = g_vMicroFacet = 0.0;
     BuildQuasiIndex(g_BlueNoiseQuasiIndex2, 2, BLUE_N);
 
-    if (name == "Venera" || name == "VeneraVenus") {        /* Venera(), Venera.cpp:626-670: frame t of 360 */
+    if (name == "Venera" || name == "VeneraVenus" || name == "VeneraAtmosphere") {        /* Venera(), Venera.cpp:626-670: frame t of 360 */
         rt.psSample = new FastBlueSamplingTile;
         rt.pcCamera = new StereographicCamera(Point3(0.0, -0.4, 9.0), 105.0);
         Solid *ps = turn(0.0, rad(has ? a : 0.0), 0.0, venera::Lander());
         rt.psModel = name == "Venera" ? venera::InLab(ps, rt) : venera::OnVenus(ps, rt);
+        if (name == "VeneraAtmosphere") rt.psModel = venera::UnderVenusAir(rt.psModel);
         return 1;
     }
     if (name == "Megacycles") {                             /* Megacycles(), Megacycles.cpp:317-349: the frame at time t in [0, 2) */
