@@ -214,6 +214,7 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     int      top;           /* first free hit slot */
     int      overflow;
     int      bail;          /* LITE interpreter met a rare, register-hungry feature: redo this ray in the FULL kernel */
+    int      mesh_slot;     /* >= 0: this ray's mesh crossings were found by k_mesh_cross, entry mesh_slot of SceneLds::mx_* */
 #ifdef RT_PHASE_PROF
     int      prof[12];      /* cycles: [1] BVH candidate search, [2] primitive tests, [3] whole intersect, [4] chain setup, [5] wrappers, [6] region fold, [7] cull_ray */
 #endif
@@ -611,6 +612,10 @@ RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena 
     hit_list(w, A, tag, prim, tp.leaf_affine);
 }
 
+/* what a workgroup of a tracing kernel keeps in LDS (scene_lds_load), and where the pre-walked mesh crossings are */
+struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int *mstack; int n_nodes, n_chains, stride;
+                  const int *mx_n; const double *mx_t; const int *mx_q; int mxcap; };     /* the pre-walked mesh crossings (RtPipe::mx_*), null = none */
+
 /* ------------------------------------------------------------------ triangle meshes (policy Q14)
  * A closed mesh is a Solid whose boundary crossings are the ray's triangle hits.  Per triangle: the Moeller-Trumbore
  * test in the form of ObjectFormat.cpp:79-102, with its two slips put right (the second barycentric test is
@@ -646,8 +651,10 @@ RT_DEV bool mesh_triangle(const RtMeshTri &T, const DRay &ray, double &t)
 #ifdef RT_MESH_COUNT        /* instrumentation build (RT_EXTRA_DEFS=-DRT_MESH_COUNT): [0] rays, [1] node visits, [2] leaf visits, [3] triangle tests, [4] wave-iterations of the node loop, [5] of the leaf loop */
 __device__ unsigned long long g_mesh_count[8];
 #define MESH_COUNT(k, v) atomicAdd(&g_mesh_count[k], (unsigned long long)(v))
+#define MESH_WAVE_COUNT(k) do { if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_mesh_count[k], 1ull); } while (0)
 #else
 #define MESH_COUNT(k, v)
+#define MESH_WAVE_COUNT(k)
 #endif
 struct MeshRay { double o[3], inv[3]; int par[3]; };      /* par: the direction component is zero */
 RT_DEV bool mesh_slot_hit(const RtMeshNode &nd, int k, const MeshRay &mr)
@@ -656,7 +663,7 @@ RT_DEV bool mesh_slot_hit(const RtMeshNode &nd, int k, const MeshRay &mr)
     bool ok = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const double lo = (double)nd.lo[a][k], hi = (double)nd.hi[a][k];
+        const double lo = (double)nd.org[a] + (double)nd.qlo[a][k] * (double)nd.scale[a], hi = (double)nd.org[a] + (double)nd.qhi[a][k] * (double)nd.scale[a];
         if (!mr.par[a]) {
             double ta = (lo - mr.o[a]) * mr.inv[a], tb = (hi - mr.o[a]) * mr.inv[a];
             const double tn = fmin(ta, tb), tf = fmax(ta, tb);
@@ -667,16 +674,38 @@ RT_DEV bool mesh_slot_hit(const RtMeshNode &nd, int k, const MeshRay &mr)
     }
     return ok && t0 <= t1;
 }
-RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag, int *lds_stack, int lds_stride)
+/* The walk.  Two phases that never interleave within a wave: (1) pop a node, test its four boxes, push the inner children
+   that are hit and QUEUE the leaf slots that are hit; (2) test the queued triangles, one per lane and iteration.  With the
+   triangle tests inside the node loop a wave ran them once per node visit for its busiest lane: measured on the
+   10 M-triangle scene, 183 triangle iterations per 64-ray wave for 10.3 tests per ray -- 6 % of the lanes busy.
+   Node stack and leaf queue share one column of `cap` LDS words per lane (entry i at [i * stride]: no bank conflicts; in
+   private memory every push and pop is a round trip through the vector memory path): the stack grows up from 0, the queue
+   down from cap - 1 (one word per leaf slot: first triangle | (count - 1) << 27); a lane whose column fills up tests its
+   queued triangles early.  Every crossing goes to the sink, unsorted.  Returns false when the stack alone outgrows the column. */
+template <class Sink>
+RT_DEV void mesh_test_queued(const RtMeshTri *tris, const DRay &ray, int *stack, const int stride, const int cap, int &lq, Sink &K)
 {
-    /* the traversal stack lives in LDS, one column per lane (entry i at [i * stride + lane]: no bank conflicts): in
-       private memory every push and pop is a round trip through the vector memory path, which then is the clock of
-       the whole walk */
-    int *const stack = lds_stack + threadIdx.x;
-#define MSTK(i) stack[(i) * lds_stride]
-    const RtMeshInfo mi = S.meshes[mp.plane0];
-    const RtMeshNode *nodes = S.mesh_nodes + mi.node0;
-    const RtMeshTri *tris = S.mesh_tris + mi.tri0;
+#define MSTK(i) stack[(i) * stride]
+    int q = 0, left = 0;
+    for (;;) {
+        if (left == 0) {
+            if (lq >= cap) break;
+            const int e = MSTK(lq); lq++;
+            q = e & 0x07FFFFFF; left = (e >> 27) + 1;
+        }
+        MESH_COUNT(3, 1);
+        MESH_WAVE_COUNT(5);
+        double t;
+        const bool hit = mesh_triangle(tris[q], ray, t);
+        if (hit) { MESH_COUNT(6, 1); K.add(t, q, tris); }
+        q++; left--;
+    }
+#undef MSTK
+}
+template <class Sink>
+RT_DEV bool mesh_walk(const RtMeshNode *nodes, const RtMeshTri *tris, const DRay &ray, int *stack, const int stride, const int cap, Sink &K)
+{
+#define MSTK(i) stack[(i) * stride]
     MeshRay mr;
     mr.o[0] = ray.org.x; mr.o[1] = ray.org.y; mr.o[2] = ray.org.z;
     {
@@ -684,51 +713,84 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
 #pragma unroll
         for (int a = 0; a < 3; a++) { mr.par[a] = d[a] == 0.0; mr.inv[a] = mr.par[a] ? 0.0 : 1.0 / d[a]; }
     }
-    double ht[RT_MESH_MAXHITS];
-    int    hq[RT_MESH_MAXHITS];         /* position in tris[] */
-    int    nh = 0, total = 0;
-    int    sp = 0;
-    /* One loop: pop a node, test its four boxes, push the inner children that are hit, and test the triangles of the
-       leaf slots that are hit through one bit mask (bit 4k + i = triangle i of slot k), so that a wave runs the
-       triangle test as many times as its busiest lane has triangles, not once per slot and position.  Crossings are
-       appended unsorted (stores do not stall; a sorted insert would load from private memory in the loop) and put
-       in (t, triangle) order once, after the walk. */
+    int sp = 0, lq = cap;
+    bool ok = true;
     MSTK(sp) = 0; sp++;
     MESH_COUNT(0, 1);
     while (sp > 0) {
         const RtMeshNode &nd = nodes[MSTK(--sp)];
         MESH_COUNT(1, 1);
+        MESH_WAVE_COUNT(4);
         bool hit[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
-        if (sp + 4 > RT_MESH_STACK) { A.overflow |= OVF_MESH_STACK; break; }
-        unsigned mask = 0;
-        int c4[4];
+        if (sp + 4 > lq) {                      /* the column is full: make room by testing what is queued */
+            mesh_test_queued(tris, ray, stack, stride, cap, lq, K);
+            if (sp + 4 > lq) { ok = false; break; }
+        }
 #pragma unroll
         for (int k = 3; k >= 0; --k) {
-            c4[k] = nd.child[k];
+            const int c = nd.child[k];
             if (!hit[k]) continue;
-            if (c4[k] >= 0) { MSTK(sp) = c4[k]; sp++; }
-            else mask |= ((1u << nd.count[k]) - 1u) << (4 * k);
-        }
-        while (mask) {
-            const int b = __builtin_ctz(mask);
-            mask &= mask - 1;
-            const int k = b >> 2;
-            const int q = ~(k == 0 ? c4[0] : k == 1 ? c4[1] : k == 2 ? c4[2] : c4[3]) + (b & 3);
-            MESH_COUNT(3, 1);
-            double t;
-            if (!mesh_triangle(tris[q], ray, t)) continue;
-            if (nh < RT_MESH_MAXHITS) { ht[nh] = t; hq[nh] = q; nh++; }
-            else {          /* rare (a ray skimming a faceted saddle): keep the RT_MESH_MAXHITS nearest, as the oracle does */
-                int m = 0;
-                for (int i = 1; i < RT_MESH_MAXHITS; i++)
-                    if (ht[i] > ht[m] || (ht[i] == ht[m] && tris[hq[i]].id > tris[hq[m]].id)) m = i;
-                if (t < ht[m] || (t == ht[m] && tris[q].id < tris[hq[m]].id)) { ht[m] = t; hq[m] = q; }
-            }
-            total++;
+            if (c >= 0) { MSTK(sp) = c; sp++; }
+            else if (c != RT_MESH_EMPTY) { --lq; MSTK(lq) = ~c; }
         }
     }
+    mesh_test_queued(tris, ray, stack, stride, cap, lq, K);
+    return ok;
+#undef MSTK
+}
+/* keeps the RT_MESH_MAXHITS nearest crossings in (t, triangle id) order of preference, in private arrays */
+struct MeshLocalSink {
+    double ht[RT_MESH_MAXHITS];
+    int    hq[RT_MESH_MAXHITS];         /* position in tris[] */
+    int    nh;
+    RT_DEV void add(double t, int q, const RtMeshTri *tris)
+    {
+        if (nh < RT_MESH_MAXHITS) { ht[nh] = t; hq[nh] = q; nh++; }
+        else {          /* rare (a ray skimming a faceted saddle): keep the RT_MESH_MAXHITS nearest, as the oracle does */
+            int m = 0;
+            for (int i = 1; i < RT_MESH_MAXHITS; i++)
+                if (ht[i] > ht[m] || (ht[i] == ht[m] && tris[hq[i]].id > tris[hq[m]].id)) m = i;
+            if (t < ht[m] || (t == ht[m] && tris[q].id < tris[hq[m]].id)) { ht[m] = t; hq[m] = q; }
+        }
+    }
+};
+/* the same rule with the crossings in global memory, entry i of a ray at [i * cap] (k_mesh_cross): a store per crossing
+   and no private array; the replacement of a 17th crossing reads the stored ones back */
+struct MeshGlobalSink {
+    double *ht; int *hq; size_t cap; int nh;
+    RT_DEV void add(double t, int q, const RtMeshTri *tris)
+    {
+        if (nh < RT_MESH_MAXHITS) { ht[nh * cap] = t; hq[nh * cap] = q; nh++; }
+        else {
+            int m = 0;
+            double tm = ht[0]; int qm = hq[0];
+            for (int i = 1; i < RT_MESH_MAXHITS; i++) {
+                const double ti = ht[i * cap]; const int qi = hq[i * cap];
+                if (ti > tm || (ti == tm && tris[qi].id > tris[qm].id)) { m = i; tm = ti; qm = qi; }
+            }
+            if (t < tm || (t == tm && tris[q].id < tris[qm].id)) { ht[m * cap] = t; hq[m * cap] = q; }
+        }
+    }
+};
+RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag, const SceneLds &L)
+{
+    const RtMeshInfo mi = S.meshes[mp.plane0];
+    const RtMeshTri *tris = S.mesh_tris + mi.tri0;
+    MeshLocalSink K;
+    K.nh = 0;
+    int pre = -1;
+    if (A.mesh_slot >= 0 && L.mx_n) pre = L.mx_n[A.mesh_slot];
+    if (pre >= 0) {                     /* found by k_mesh_cross: the same walk, run in a kernel of its own */
+        for (int i = 0; i < pre; i++) { K.ht[i] = L.mx_t[(size_t)i * L.mxcap + A.mesh_slot]; K.hq[i] = L.mx_q[(size_t)i * L.mxcap + A.mesh_slot]; }
+        K.nh = pre;
+    } else if (!mesh_walk(S.mesh_nodes + mi.node0, tris, ray, L.mstack + threadIdx.x, L.stride, RT_MESH_STACK, K)) {
+        A.overflow |= OVF_MESH_STACK;
+    }
+    double *const ht = K.ht;
+    int *const hq = K.hq;
+    const int nh = K.nh;
     /* insertion sort, order (t, triangle id) */
     for (int i = 1; i < nh; i++) {
         const double t = ht[i];
@@ -737,7 +799,6 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
         for (; j > 0 && (t < ht[j - 1] || (t == ht[j - 1] && id < tris[hq[j - 1]].id)); --j) { ht[j] = ht[j - 1]; hq[j] = hq[j - 1]; }
         ht[j] = t; hq[j] = q;
     }
-    (void)total;
     if (nh == 0) return;
     MeshWork w;
     w.inside_inf = 0; w.eps = RT_EPSILON;
@@ -750,7 +811,6 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
     }
     w.count = nh + behind;
     hit_list(w, A, tag, prim, mp.leaf_affine);
-#undef MSTK
 }
 
 /* ================================================================== CSG merge (Solids.cpp:987-1058) */
@@ -843,7 +903,6 @@ RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
 /* workgroup-shared staging in dynamic LDS: the first n_nodes nodes of the scene's BVH, the scene's chain records
    (persistent kernels, when they all fit), then the per-lane traversal stacks (RT_BVH_STACK x blockDim.x x 2 B).
    The host sizes the allocation (rt_scene_upload: lds_small / lds_visual / lds_shadow). */
-struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int *mstack; int n_nodes, n_chains, stride; };
 #define RT_LDS_STACK(L, sp, lane) (L).stack[(sp) * (L).stride + (lane)]
 /* every thread of the workgroup must call this before intersect_scene */
 /* 8-byte words of LDS the small scene tables take when staged (same arithmetic on the host: rt_scene_upload) */
@@ -878,6 +937,7 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_packed, RtDevSc
 {
     extern __shared__ double rt_dyn_lds[];
     SceneLds L;
+    L.mx_n = 0; L.mx_t = 0; L.mx_q = 0; L.mxcap = 0;
     const int groups = (n_chains_packed >> 24) & 3;         /* bit 28 belongs to k_visual (primary level) */
     L.n_nodes = S.n_bvh_lds;
     L.n_chains = n_chains_packed & 0xFFFFFF;
@@ -1006,9 +1066,10 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
 template <bool LITE, bool CH_LDS = false, bool TILES = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
-                               const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1)
+                               const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
 {
     DRay rs[RT_MAX_AFFINE_DEPTH + 1];
+    A.mesh_slot = mesh_slot;
     RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 }, saved[RT_MAX_REGION_DEPTH];
     uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
     int nrf = 0;
@@ -1073,7 +1134,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MESH:
             if constexpr (LITE) { A.bail = 1; goto done; }
-            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L.mstack, L.stride); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -1182,7 +1243,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 default:
                     if constexpr (LITE) { A.bail = 1; goto done; }
                     else {
-                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag, L.mstack, L.stride);
+                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag, L);
                         else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }

@@ -162,18 +162,22 @@ typedef struct RtChain {
     int32_t wrap_tex[RT_CHAIN_WRAPS];   /* texture call-out the wrapper queues, -1 none */
 } RtChain;
 
-/* Triangle meshes (policy Q14).  One 4-wide BVH per mesh over its triangles, in the mesh's own frame: a node is one
-   128-byte line holding four child boxes (floats rounded outward) that are tested together -- half the dependent loads
-   of a binary tree, and the four slab tests are independent arithmetic.  Triangles are stored in leaf order as
-   (v0, e1, e2) with the edges subtracted once on the host -- ObjectFormat.cpp:85-86 subtracts them per test, same
-   doubles either way. */
+/* Triangle meshes (policy Q14).  One 4-wide BVH per mesh over its triangles, in the mesh's own frame: a node is 64 bytes
+   holding four child boxes that are tested together -- half the dependent loads of a binary tree, and the four slab tests
+   are independent arithmetic.  The boxes are 8-bit offsets on a per-node grid (org + q * scale per axis, lower corners
+   rounded down and upper ones up, so a decoded box contains the child's float box, which contains its triangles): a walk
+   is a chain of divergent node reads, and what bounds it is how many 16-byte pieces the texture path has to fetch per lane
+   and how many nodes the caches hold -- measured on the 10 M-triangle scene: 128-byte nodes with float boxes took 8 vector
+   loads per visit and missed L2 on 40 % of them.  Triangles are stored in leaf order as (v0, e1, e2) with the edges
+   subtracted once on the host -- ObjectFormat.cpp:85-86 subtracts them per test, same doubles either way. */
 #define RT_MESH_MAXHITS 16          /* MAXHITS, Solids.h:20: crossings kept per ray and mesh (the nearest ones) */
 #define RT_MESH_STACK   48          /* pending BVH entries per ray (LDS, 4 B each): 3 per level + 1, 2^27 triangles = 13 levels */
 #define RT_MESH_LEAF    4           /* triangles per leaf at most */
-typedef struct __attribute__((aligned(128))) RtMeshNode {
-    float   lo[3][4], hi[3][4];
-    int32_t child[4];       /* >= 0: node index relative to the mesh's first node; < 0: leaf, first triangle = ~child */
-    int32_t count[4];       /* leaf: triangles (0 = unused slot) */
+#define RT_MESH_EMPTY   ((int32_t)0x80000000)      /* unused child slot (its box is inverted: never hit) */
+typedef struct __attribute__((aligned(64))) RtMeshNode {
+    float   org[3], scale[3];           /* the node's grid: coordinate = org + q * scale, q in 0..255 */
+    uint8_t qlo[3][4], qhi[3][4];       /* [axis][slot] */
+    int32_t child[4];       /* >= 0: node index relative to the mesh's first node; RT_MESH_EMPTY: unused; else a leaf: ~child = first triangle | (count - 1) << 27 */
 } RtMeshNode;
 typedef struct RtMeshTri {
     double  v0[3], e1[3], e2[3];
@@ -236,4 +240,9 @@ typedef struct RtDevScene {
     const int32_t    *root_alt_pc;          /* root_cull == 1: per child of the root region, pc of "that chain for the root consumer; OP_END" behind the program, -1 = the child is not a bare chain */
     int32_t           n_root_alt, root_child_pc0;
     const int32_t    *root_fast;            /* root_cull == 1: per child of the root region, the chain k_fast may run for a primary ray that can touch this child alone, -1 = not eligible; null = no fast path */
+    /* the mesh pre-walk (k_mesh_cross): the program holds exactly ONE mesh instruction, reached through the affines
+       mesh_pre_aff[0 .. mesh_pre_naff) (outermost first) and, when the mesh is a chain's primitive, that chain's own affine;
+       mesh_pre_naff < 0 = no pre-walk (no mesh, or more than one) */
+    int32_t           mesh_pre_naff, mesh_pre_chain, mesh_pre_mesh, pad2_;
+    int32_t           mesh_pre_aff[RT_MAX_AFFINE_DEPTH];
 } RtDevScene;

@@ -253,7 +253,7 @@ struct Flattener {
             std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
                              [&C, ax](int x, int y) { float cx = C[3 * (size_t)x + ax], cy = C[3 * (size_t)y + ax]; return cx < cy || (cx == cy && x < y); });
         }
-        void range_box(int first, int count, RtMeshNode &nd, int slot) const
+        void range_box(int first, int count, float flo[3], float fhi[3]) const
         {
             double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
             for (int q = first; q < first + count; q++) {
@@ -266,7 +266,30 @@ struct Flattener {
                 float l = (float)(lo[k] - e), h = (float)(hi[k] + e);
                 if ((double)l > lo[k] - e) l = nextafterf(l, -INFINITY);
                 if ((double)h < hi[k] + e) h = nextafterf(h, INFINITY);
-                nd.lo[k][slot] = l; nd.hi[k][slot] = h;
+                flo[k] = l; fhi[k] = h;
+            }
+        }
+        /* the node's grid and the children's 8-bit corners on it: every decoded corner (evaluated as the device does, in
+           double) lies outside the child's float box */
+        static void quantize(RtMeshNode &nd, int nr, const float (*blo)[3], const float (*bhi)[3])
+        {
+            for (int a = 0; a < 3; a++) {
+                double ulo = 1e300, uhi = -1e300;
+                for (int k = 0; k < nr; k++) { if (blo[k][a] < ulo) ulo = blo[k][a]; if (bhi[k][a] > uhi) uhi = bhi[k][a]; }
+                float org = (float)ulo;
+                if ((double)org > ulo) org = nextafterf(org, -INFINITY);
+                float sc = (float)((uhi - (double)org) / 255.0);
+                if (!(sc > 0.0f)) sc = 1e-30f;
+                while ((double)org + 255.0 * (double)sc < uhi) sc = nextafterf(sc, INFINITY);
+                nd.org[a] = org; nd.scale[a] = sc;
+                for (int k = 0; k < 4; k++) {
+                    if (k >= nr) { nd.qlo[a][k] = 255; nd.qhi[a][k] = 0; continue; }       /* unused slot: an inverted box */
+                    int ql = (int)floor(((double)blo[k][a] - (double)org) / (double)sc), qh = (int)ceil(((double)bhi[k][a] - (double)org) / (double)sc);
+                    ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                    while (ql > 0 && (double)org + (double)ql * (double)sc > (double)blo[k][a]) ql--;
+                    while (qh < 255 && (double)org + (double)qh * (double)sc < (double)bhi[k][a]) qh++;
+                    nd.qlo[a][k] = (uint8_t)ql; nd.qhi[a][k] = (uint8_t)qh;
+                }
             }
         }
         int build(int first, int count)
@@ -275,7 +298,7 @@ struct Flattener {
             nodes->push_back(RtMeshNode());
             RtMeshNode nd;
             memset(&nd, 0, sizeof nd);
-            for (int k = 0; k < 4; k++) { nd.child[k] = -1; nd.count[k] = 0; for (int a = 0; a < 3; a++) { nd.lo[a][k] = 1.0f; nd.hi[a][k] = -1.0f; } }
+            for (int k = 0; k < 4; k++) nd.child[k] = RT_MESH_EMPTY;
             int r0[4], rc[4], nr = 0;
             if (count <= RT_MESH_LEAF) { r0[0] = first; rc[0] = count; nr = 1; }
             else {
@@ -292,11 +315,13 @@ struct Flattener {
                     }
                 }
             }
+            float blo[4][3], bhi[4][3];
             for (int k = 0; k < nr; k++) {
-                range_box(r0[k], rc[k], nd, k);
-                if (rc[k] <= RT_MESH_LEAF) { nd.child[k] = ~r0[k]; nd.count[k] = rc[k]; }
-                else { nd.child[k] = build(r0[k], rc[k]); nd.count[k] = 0; }
+                range_box(r0[k], rc[k], blo[k], bhi[k]);
+                if (rc[k] <= RT_MESH_LEAF) nd.child[k] = ~(r0[k] | ((rc[k] - 1) << 27));
+                else nd.child[k] = build(r0[k], rc[k]);
             }
+            quantize(nd, nr, blo, bhi);
             (*nodes)[node0 + me] = nd;
             return me;
         }
@@ -306,7 +331,7 @@ struct Flattener {
         const RtNode &n = N(i);
         const double *p = D(i);
         const int nv = n.i0, nt = n.i1;
-        if (nt > (1 << 27)) { fail(RT_ERR_UNSUPPORTED, "mesh of more than 2^27 triangles"); return -1; }
+        if (nt >= (1 << 27)) { fail(RT_ERR_UNSUPPORTED, "mesh of 2^27 triangles or more"); return -1; }
         if (nv < 3 || nt < 1 || n.ndata != 3 * nv + 3 * nt) { fail(RT_ERR_INVALID, "mesh node with inconsistent sizes"); return -1; }
         const double *f = p + 3 * (size_t)nv;
         for (size_t k = 0; k < 3 * (size_t)nt; k++)

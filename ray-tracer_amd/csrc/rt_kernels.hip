@@ -727,8 +727,9 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;
-    const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
+    SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
+    if constexpr (!LITE) if (f1 <= f0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }     /* slow list: k_mesh_cross went first */
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
     /* LITE && TILES (the primary level of a pass with tile lists) with RT_BOUND_ON_DEVICE in n_chains_lds: [f0, f1) is an
@@ -796,7 +797,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                 if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
             }
         }
-        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one);
+        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one, (!LITE && !direct) ? wbase + wlane : -1);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
@@ -1146,13 +1147,170 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
 
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
+/* ------------------------------------------------------------------ k_mesh_cross: the mesh walk in a kernel of its own
+ * The FULL kernels carry the whole interpreter, shading and the rare features: 256 registers, two waves per SIMD -- and a
+ * mesh walk is a chain of dependent 128-byte node reads that wants many rays in flight.  For scenes whose program holds one
+ * mesh instruction, the rays of a slow list (what the LITE launch handed over) are walked here first: the ray is taken into
+ * the mesh's frame by the same affines in the same order as the interpreter would (bit-identical), the same walk runs with
+ * a stack of RT_MESHPRE_STACK entries in LDS, and every crossing is stored as it is found (no private arrays, no sort: the
+ * FULL kernel's mesh_hits reads them back, orders them and builds the hit list as it would have after walking itself).
+ * A ray whose walk runs out of stack is marked -1 and walked again in line. */
+#define RT_MESHPRE_STACK   32          /* LDS words per lane: node stack from the bottom, leaf queue from the top */
+#define RT_MESHPRE_THREADS 256
+#define RT_MESHPRE_ROUND   128         /* triangle tests a wave shares out per round */
+#define RT_MESHPRE_LDS     ((RT_MESHPRE_STACK * RT_MESHPRE_THREADS + (RT_MESHPRE_THREADS / 64) * (64 + 2 * RT_MESHPRE_ROUND)) * (int)sizeof(int))
+/* A crossing found by any lane for the ray of lane `owner` of the same wave: counted in LDS, stored in the owner's record
+   while it has room (a 17th crossing makes the FULL kernel walk that ray again in line -- rare). */
+RT_DEV void mesh_cross_emit(const RtPipe &P, int *wave_nh, const int slot0, const int owner, const double t, const int q)
+{
+    const int k = atomicAdd(&wave_nh[owner], 1);
+    if (k < RT_MESH_MAXHITS) {
+        P.mx_t[(size_t)k * P.mxcap + slot0 + owner] = t;
+        P.mx_q[(size_t)k * P.mxcap + slot0 + owner] = q;
+    }
+}
+template <bool SHADOW>
+__global__ void __launch_bounds__(RT_MESHPRE_THREADS, 4) k_mesh_cross(const RtDevScene S, RtPipe P)
+{
+    extern __shared__ int mx_lds[];
+    const int n = P.counters[SHADOW ? CTR_SLOW_S : CTR_SLOW_V];
+    int *const work = &P.counters[SHADOW ? CTR_WORK_MS : CTR_WORK_MV];
+    const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *const stack = mx_lds + threadIdx.x;                        /* entry i at [i * RT_MESHPRE_THREADS] */
+    int *const wave_nh = mx_lds + RT_MESHPRE_STACK * RT_MESHPRE_THREADS + wave * (64 + 2 * RT_MESHPRE_ROUND);
+    int *const buf_q = wave_nh + 64, *const buf_o = buf_q + RT_MESHPRE_ROUND;
+#define MSTK(i) stack[(i) * RT_MESHPRE_THREADS]
+    const RtMeshInfo mi = S.meshes[S.mesh_pre_mesh];
+    const RtMeshNode *nodes = S.mesh_nodes + mi.node0;
+    const RtMeshTri *tris = S.mesh_tris + mi.tri0;
+    for (;;) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, 64);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        const int slot = b + wlane;
+        const bool live = slot < n;
+        DRay ray;
+        ray.org = d3(0.0, 0.0, 0.0); ray.dir = d3(0.0, 0.0, 1.0);
+        if (live) {
+            if (SHADOW) { const int s = P.slow_s[slot]; ray.org = d3_fetch(P.s_ray, P.scap, 0, s); ray.dir = d3_fetch(P.s_ray, P.scap, 3, s); }
+            else { const int f = P.slow_v[slot]; ray.org = d3_fetch(P.f_ray, P.fcap, 0, f); ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f); }
+            for (int k = 0; k < S.mesh_pre_naff; k++) {                 /* AffineSolid::Intersect (Solids.cpp:899-913), as OP_PUSH_AFFINE does it */
+                const RtAffine &a = S.affines[S.mesh_pre_aff[k]];
+                DRay nr;
+                nr.dir = mat_vec(a.minv, ray.dir);
+                nr.org = mat_vec(a.minv, ray.org - d3(a.tr[0], a.tr[1], a.tr[2]));
+                ray = nr;
+            }
+            if (S.mesh_pre_chain >= 0) {                                /* ... and as OP_CHAIN does it */
+                const RtChain &ch = S.chains[S.mesh_pre_chain];
+                if (ch.n_affine) {
+                    DRay nr;
+                    nr.dir = mat_vec(ch.minv, ray.dir);
+                    nr.org = mat_vec(ch.minv, ray.org - d3(ch.tr[0], ch.tr[1], ch.tr[2]));
+                    ray = nr;
+                }
+            }
+        }
+        wave_nh[wlane] = 0;
+        /* phase 1, per lane: the node walk; leaf slots that are hit are queued (first triangle | (count - 1) << 27) */
+        int sp = 0, lq = RT_MESHPRE_STACK, ntri = 0;
+        bool ok = true;
+        if (live) { MSTK(0) = 0; sp = 1; MESH_COUNT(0, 1); }
+        MeshRay mr;
+        mr.o[0] = ray.org.x; mr.o[1] = ray.org.y; mr.o[2] = ray.org.z;
+        {
+            const double d[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
+#pragma unroll
+            for (int a = 0; a < 3; a++) { mr.par[a] = d[a] == 0.0; mr.inv[a] = mr.par[a] ? 0.0 : 1.0 / d[a]; }
+        }
+        while (sp > 0) {
+            const RtMeshNode &nd = nodes[MSTK(--sp)];
+            MESH_COUNT(1, 1);
+            MESH_WAVE_COUNT(4);
+            bool hit[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
+            if (sp + 4 > lq) {                  /* the column is full: this lane tests what it has queued, alone */
+                while (lq < RT_MESHPRE_STACK) {
+                    const int e = MSTK(lq); lq++;
+                    const int q0 = e & 0x07FFFFFF, c = (e >> 27) + 1;
+                    for (int k = 0; k < c; k++) {
+                        double t;
+                        MESH_COUNT(3, 1);
+                        if (mesh_triangle(tris[q0 + k], ray, t)) { MESH_COUNT(6, 1); mesh_cross_emit(P, wave_nh, b, wlane, t, q0 + k); }
+                    }
+                }
+                ntri = 0;
+                if (sp + 4 > lq) { ok = false; break; }
+            }
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const int c = nd.child[k];
+                if (!hit[k]) continue;
+                if (c >= 0) { MSTK(sp) = c; sp++; }
+                else if (c != RT_MESH_EMPTY) { --lq; MSTK(lq) = ~c; ntri += ((~c) >> 27) + 1; }
+            }
+        }
+        /* phase 2, the whole wave: the queued triangle tests of all 64 rays are dealt out evenly.  A skimming ray queues a
+           hundred triangles where the average ray has ten (measured: 124 iterations per wave with every lane testing its
+           own); shared out, a wave needs its total / 64.  Item i of the wave's list belongs to the lane whose prefix range
+           holds i; rounds of RT_MESHPRE_ROUND items go through LDS as (triangle, owner), the owner's ray comes by shuffle. */
+        int incl = ntri;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (wlane >= d) incl += v; }
+        const int total = __shfl(incl, 63, 64);
+        int next = incl - ntri;                 /* the list index of this lane's next triangle */
+        int q_cur = 0, left = 0;
+        for (int base = 0; base < total; base += RT_MESHPRE_ROUND) {
+            const int end = base + RT_MESHPRE_ROUND;
+            while (next < incl && next < end) {
+                if (left == 0) { const int e = MSTK(lq); lq++; q_cur = e & 0x07FFFFFF; left = (e >> 27) + 1; }
+                buf_q[next - base] = q_cur; buf_o[next - base] = wlane;
+                q_cur++; left--; next++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int cnt = total - base < RT_MESHPRE_ROUND ? total - base : RT_MESHPRE_ROUND;
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int i = i0 + wlane;
+                const bool act = i < cnt;
+                const int o = act ? buf_o[i] : wlane, q = act ? buf_q[i] : 0;
+                DRay r;
+                r.org = d3(__shfl(ray.org.x, o, 64), __shfl(ray.org.y, o, 64), __shfl(ray.org.z, o, 64));
+                r.dir = d3(__shfl(ray.dir.x, o, 64), __shfl(ray.dir.y, o, 64), __shfl(ray.dir.z, o, 64));
+                MESH_WAVE_COUNT(5);
+                if (act) {
+                    double t;
+                    MESH_COUNT(3, 1);
+                    if (mesh_triangle(tris[q], r, t)) { MESH_COUNT(6, 1); mesh_cross_emit(P, wave_nh, b, o, t, q); }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (live) {
+            const int nh = wave_nh[wlane];
+            P.mx_n[slot] = (ok && nh <= RT_MESH_MAXHITS) ? nh : -1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef MSTK
+}
+template __global__ void k_mesh_cross<false>(const RtDevScene, RtPipe);
+template __global__ void k_mesh_cross<true>(const RtDevScene, RtPipe);
+
 template <bool LITE, int MODE>
 __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
     RtDevScene SL = Sv;
-    const SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
+    SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
+    if constexpr (!LITE) if (nrays == 0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }       /* slow list: k_mesh_cross went first */
     if (LITE && nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
     const bool direct = LITE || nrays > 0;      /* FULL: nrays == 0 = the slow list of the LITE launch before it */
     const int n = direct ? nrays : P.counters[CTR_SLOW_S];
@@ -1186,7 +1344,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
         Arena A;
         int start;
-        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, 1.0, A, start);
+        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, 1.0, A, start, 0, 0, -1, (!LITE && !direct) ? wbase + wlane : -1);
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
         int i = 0, pm = 0;

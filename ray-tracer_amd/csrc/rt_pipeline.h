@@ -35,7 +35,8 @@ enum { IDS_ROUGH = 0, IDS_LUSTER = 1, IDS_SHBASE = 2, IDS_SHMASK = 3, IDS_COUNT 
 enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * CTR_LINE, CTR_SLOW_V = 2 * CTR_LINE + 1, CTR_SLOW_S = 4 * CTR_LINE,
        CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
        CTR_FAST = 10 * CTR_LINE, CTR_WORK_F = 11 * CTR_LINE, CTR_SNAP = 12 * CTR_LINE, CTR_WORK_SH = 13 * CTR_LINE,
-       CTR_COUNT = 14 * CTR_LINE };
+       CTR_WORK_MV = 14 * CTR_LINE, CTR_WORK_MS = 15 * CTR_LINE,      /* k_mesh_cross over the visual / shadow slow list: cleared per level by the host */
+       CTR_COUNT = 16 * CTR_LINE };
 #define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
 #ifndef RT_CLAIM
 #define RT_CLAIM 128        /* items a persistent wave claims per atomic: two 64-item passes.  Same box, 4K / 64 spp: 512 / 256 / 128 / 64 items =
@@ -65,6 +66,12 @@ typedef struct RtPipe {
        recomputes the ray from the sample index, keeps the (at most three) hits in registers and, where no shadow ray or
        child ray is needed, shades and delivers the sample without ever making a frame.  2 x ncap ints: [k][chain]. */
     int    *fast_q;
+    /* the mesh pre-walk (scenes with RtDevScene.mesh_pre_naff >= 0): for entry k of the slow list that the FULL kernel is
+       about to work through, the triangle crossings of its ray with the scene's mesh -- mx_n[k] of them (-1: the walk ran out
+       of stack, walk again in line), unsorted, crossing i at [i * mxcap + k]: distance and position in mesh_tris.  Written by
+       k_mesh_cross between the LITE and the FULL launch, for the visual rays and then again for the shadow rays of a level. */
+    int    *mx_n; double *mx_t; int *mx_q;
+    int     mxcap, pad2_;
     /* the sampling tiles' candidate lists (RtSampleGrid::tile_mask / tile_cand) for the PRIMARY rays of this chunk: root
        sample k of the chunk lies in tile (tile_first + k) / 1600.  Null = none. */
     const unsigned char  *tile_n;

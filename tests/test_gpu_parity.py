@@ -592,6 +592,37 @@ def test_mesh_at_scale_converges_to_the_quadric(gpu):
     assert _rel_rmse(a, b) < 2e-2 and np.abs(a - b).mean() < 1e-3 * b.mean() + 1e-4
 
 
+ONE_MESH = """(scene
+ (model (union
+   (rotate 0.5 0.3 0 (material 0.9 auto g_sOrange plastic none none (surface shiny none (translate 0.2 0 0 (scale 1.1 0.9 1 (meshblob 200 101 0.08 5))))))
+   (translate 0 1.6 -1 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (arealight 1.0 9 -6.5 12 (scale (blackbody 6500) 8000))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 2000))
+ (camera perspective 0 0 6 40) (sampler fastblue))"""
+
+
+@pytest.mark.parametrize("wrap", ["plain", "glass"])
+def test_mesh_pre_walk_is_invisible(gpu, oracle, wrap):
+    """k_mesh_cross (scenes with one mesh instruction: the rays the LITE kernels hand over are walked through the mesh's BVH
+    in a kernel of its own, the FULL kernels read the crossings): frames, ray counts equal with the pre-walk off and on, and
+    equal to the oracle's brute force over all triangles.  `glass`: the mesh as a transparent polished solid, so that
+    secondary rays start on and inside it."""
+    scene = ONE_MESH if wrap == "plain" else ONE_MESH.replace("(material 0.9 auto g_sOrange plastic none none (surface shiny none", "(material 0.9 1.5 g_sWhite transparent none none (surface polished none")
+    out = []
+    for on in (0, 1):
+        gpu.set_options({"mesh_pre": on})
+        fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+        img, st = gpu.GpuScene(fs.desc).render(160, 90, 4)
+        assert st.hit_overflow == 0
+        out.append((img, (st.rays_primary, st.rays_shadow, st.rays_secondary)))
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+    raw = gpu.FrontScene(scene, "fastblue", optimize=False)
+    ost = gpu.RtStats()
+    ref, _, n = oracle.OracleScene(raw.desc).render(160, 90, 4, gpu.RtRenderDesc(160, 90, 4.0, 0, 0), ost, threads=16)
+    assert out[1][1] == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary) and np.array_equal(out[1][0], ref)
+
+
 def test_mesh_keeps_the_nearest_sixteen_crossings(gpu, oracle):
     """MAXHITS (Solids.h:20) for meshes, policy Q14: a ray that crosses one mesh more than sixteen times keeps the sixteen
     nearest crossings, on the device as in the oracle (ten cubes in a row as ONE mesh: twenty crossings down the axis)."""

@@ -12,7 +12,8 @@ if not hasattr(L, 'rt_debug_mesh_counts'):
     raise SystemExit(__doc__)
 W,H,spp = 960,540,4.0
 planes = torch.zeros((3,H,W), dtype=torch.float32, device="cuda")
-for name, body in (("ico","(meshicosahedron)"),("1.6K","(meshblob 40 21 0.08 5)"),("100K","(meshblob 320 157 0.08 5)"),("1M","(meshblob 1000 501 0.08 5)"),("sph100K","(meshsphere 320 157)")):
+CASES = (("ico","(meshicosahedron)"),("1.6K","(meshblob 40 21 0.08 5)"),("100K","(meshblob 320 157 0.08 5)"),("1M","(meshblob 1000 501 0.08 5)"),("sph100K","(meshsphere 320 157)"),("10M","(meshblob 3200 1563 0.08 5)"))
+for name, body in [c for c in CASES if len(sys.argv) < 2 or c[0] in sys.argv[1:]]:
     fs = rt.FrontScene(bench.MESH_SCENE.replace("(meshblob %d %d 0.08 5)", body), "fastblue", optimize=True)
     gs = rt.GpuScene(fs.desc)
     out = (C.c_ulonglong*8)()
@@ -21,4 +22,4 @@ for name, body in (("ico","(meshicosahedron)"),("1.6K","(meshblob 40 21 0.08 5)"
     torch.cuda.synchronize()
     L.rt_debug_mesh_counts(out, 1)
     r = max(1,out[0])
-    print("%-8s mesh rays %9d  nodes/ray %6.1f  leaves/ray %6.1f  tris/ray %6.1f  wave node-iters/ray*64 %7.1f  wave leaf-iters/ray*64 %7.1f" % (name, out[0], out[1]/r, out[2]/r, out[3]/r, out[4]*64/r, out[5]*64/r))
+    print("%-8s rays %d (shadow %d)  mesh rays %9d  nodes/ray %6.1f  tris/ray %6.1f  crossings/ray %5.2f  wave node-iters per ray-wave %7.1f  wave leaf-iters per ray-wave %7.1f" % (name, st.rays(), st.rays_shadow, out[0], out[1]/r, out[3]/r, out[6]/r, out[4]*64/r, out[5]*64/r))
