@@ -1157,6 +1157,12 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
  * A ray whose walk runs out of stack is marked -1 and walked again in line. */
 #define RT_MESHPRE_STACK   32          /* LDS words per lane: node stack from the bottom, leaf queue from the top */
 #define RT_MESHPRE_THREADS 256
+#ifndef RT_MESHPRE_NODES
+#define RT_MESHPRE_NODES   2
+#endif
+#ifndef RT_MESHPRE_WAVES
+#define RT_MESHPRE_WAVES   4           /* waves per SIMD the kernel is built for */
+#endif
 #define RT_MESHPRE_ROUND   128         /* triangle tests a wave shares out per round */
 #define RT_MESHPRE_LDS     ((RT_MESHPRE_STACK * RT_MESHPRE_THREADS + (RT_MESHPRE_THREADS / 64) * (64 + 2 * RT_MESHPRE_ROUND)) * (int)sizeof(int))
 /* A crossing found by any lane for the ray of lane `owner` of the same wave: counted in LDS, stored in the owner's record
@@ -1170,7 +1176,7 @@ RT_DEV void mesh_cross_emit(const RtPipe &P, int *wave_nh, const int slot0, cons
     }
 }
 template <bool SHADOW>
-__global__ void __launch_bounds__(RT_MESHPRE_THREADS, 4) k_mesh_cross(const RtDevScene S, RtPipe P)
+__global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_cross(const RtDevScene S, RtPipe P)
 {
     extern __shared__ int mx_lds[];
     const int n = P.counters[SHADOW ? CTR_SLOW_S : CTR_SLOW_V];
@@ -1224,14 +1230,20 @@ __global__ void __launch_bounds__(RT_MESHPRE_THREADS, 4) k_mesh_cross(const RtDe
 #pragma unroll
             for (int a = 0; a < 3; a++) { mr.par[a] = d[a] == 0.0; mr.inv[a] = mr.par[a] ? 0.0 : 1.0 / d[a]; }
         }
+        /* RT_MESHPRE_NODES nodes per iteration: the order in which pending nodes are visited does not matter (every crossing
+           is collected), so a lane with several pending nodes has as many node reads in flight and needs that many fewer
+           iterations -- the walk waits on memory, and reads in flight are what it is short of */
         while (sp > 0) {
-            const RtMeshNode &nd = nodes[MSTK(--sp)];
-            MESH_COUNT(1, 1);
-            MESH_WAVE_COUNT(4);
-            bool hit[4];
+            int idx[RT_MESHPRE_NODES];
+            int nn = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
-            if (sp + 4 > lq) {                  /* the column is full: this lane tests what it has queued, alone */
+            for (int h = 0; h < RT_MESHPRE_NODES; h++) { const bool have = sp > 0; idx[h] = have ? MSTK(sp - 1) : idx[0]; if (have) { --sp; nn++; } }
+            RtMeshNode nds[RT_MESHPRE_NODES];
+#pragma unroll
+            for (int h = 0; h < RT_MESHPRE_NODES; h++) nds[h] = nodes[idx[h]];
+            MESH_COUNT(1, nn);
+            MESH_WAVE_COUNT(4);
+            if (sp + 4 * RT_MESHPRE_NODES > lq) {                  /* the column is full: this lane tests what it has queued, alone */
                 while (lq < RT_MESHPRE_STACK) {
                     const int e = MSTK(lq); lq++;
                     const int q0 = e & 0x07FFFFFF, c = (e >> 27) + 1;
@@ -1242,14 +1254,22 @@ __global__ void __launch_bounds__(RT_MESHPRE_THREADS, 4) k_mesh_cross(const RtDe
                     }
                 }
                 ntri = 0;
-                if (sp + 4 > lq) { ok = false; break; }
+                if (sp + 4 * RT_MESHPRE_NODES > lq) { ok = false; break; }
             }
 #pragma unroll
-            for (int k = 3; k >= 0; --k) {
-                const int c = nd.child[k];
-                if (!hit[k]) continue;
-                if (c >= 0) { MSTK(sp) = c; sp++; }
-                else if (c != RT_MESH_EMPTY) { --lq; MSTK(lq) = ~c; ntri += ((~c) >> 27) + 1; }
+            for (int h = 0; h < RT_MESHPRE_NODES; h++) {
+                const RtMeshNode &nd = nds[h];
+                if (h >= nn) break;
+                bool hit[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) hit[k] = mesh_slot_hit(nd, k, mr);
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const int c = nd.child[k];
+                    if (!hit[k]) continue;
+                    if (c >= 0) { MSTK(sp) = c; sp++; }
+                    else if (c != RT_MESH_EMPTY) { --lq; MSTK(lq) = ~c; ntri += ((~c) >> 27) + 1; }
+                }
             }
         }
         /* phase 2, the whole wave: the queued triangle tests of all 64 rays are dealt out evenly.  A skimming ray queues a
