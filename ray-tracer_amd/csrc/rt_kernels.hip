@@ -1331,8 +1331,9 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
     if constexpr (!LITE) if (nrays == 0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }       /* slow list: k_mesh_cross went first */
-    if (LITE && nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
-    const bool direct = LITE || nrays > 0;      /* FULL: nrays == 0 = the slow list of the LITE launch before it */
+    const bool slow_list = !LITE && nrays == 0;     /* FULL: nrays == 0 = the slow list of the LITE launch before it */
+    if (nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
+    const bool direct = !slow_list;
     const int n = direct ? nrays : P.counters[CTR_SLOW_S];
     int *const work = &P.counters[LITE ? CTR_WORK_S : CTR_WORK_SS];
     const int wlane = threadIdx.x & 63;
