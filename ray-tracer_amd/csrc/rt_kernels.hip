@@ -1717,6 +1717,7 @@ __global__ void __launch_bounds__(256) k_splat_gather(const RtDevScene Sv, RtSam
         if (tx < g.tiles_x && ty >= 0 && ty < g.tiles_y_local) needed = g.tile_need[tx * g.tiles_y_local + ty] != 0;
     }
     if (needed) splat_pixel(Sv, g, T, sample_rgb, px, py, r, gg, b, w);
+    else if (g.need_lazy) return;           /* never read: k_resample_rows takes this pixel as the zero it would hold */
     size_t rows = (size_t)(y1 - y0), o = (size_t)(py - y0) * g.nW + px;
     im2[o] = r; im2[rows * g.nW + o] = gg; im2[2 * rows * g.nW + o] = b;
     wt2[o] = w;
@@ -1944,7 +1945,15 @@ __global__ void __launch_bounds__(256) k_adapt_direct(const float *im2, const fl
 #define RT_RS_IDX(j) ((j) + ((j) >> 5))
 /* need (optional, FastBlue): RtSampleGrid::tile_need with its geometry.  A destination all of whose source pixels lie in
    tiles that cannot matter reads zeros only: the zero it would compute (+0 / wsum) is written without the tap loop. */
-struct RtNeedMap { const unsigned char *need; int tiles_x, tiles_y_local, tile_row0 /* tile_y0 * 40 - src_y0: local source row where tile row 0 begins */; };
+struct RtNeedMap { const unsigned char *need; int tiles_x, tiles_y_local, tile_row0 /* tile_y0 * 40 - src_y0: local source row where tile row 0 begins */;
+                   int lazy /* pixels of tiles with need == 0 were not written by the gather: they are zeros by definition, never loaded */; };
+/* is supersample pixel x of local source row `row` one the splat gather left unwritten (k_splat_gather's own rule)? */
+RT_DEV bool need_unwritten(const RtNeedMap &nd, int x, int row)
+{
+    if (!nd.lazy || row < nd.tile_row0) return false;
+    const int tx = x / RT_BLUE_NSQRT, ty = (row - nd.tile_row0) / RT_BLUE_NSQRT;
+    return tx < nd.tiles_x && ty < nd.tiles_y_local && nd.need[tx * nd.tiles_y_local + ty] == 0;
+}
 RT_DEV bool need_any(const RtNeedMap &nd, int x0, int x1, int n_src, int ty0, int ty1)
 {
     if (ty0 < 0 || ty1 >= nd.tiles_y_local) return true;
@@ -1966,11 +1975,32 @@ __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int pla
     const int base = T.first[id0], span = T.first[last] + T.count[last] - base;
     const bool staged = span > 0 && span <= RT_RS_SPAN;
     const bool utaps = T.uniform && T.max_count <= RT_RS_TAPS;
+    /* lazy rows: which of the tiles this workgroup's span touches were written at all (one flag per tile, in LDS); when
+       none was, every destination is the zero it would compute from zeros: written without staging anything */
+    __shared__ unsigned char s_need[RT_RS_SPAN / RT_BLUE_NSQRT + 3];
+    const bool lazy = staged && nd.lazy && row >= nd.tile_row0 && (row - nd.tile_row0) / RT_BLUE_NSQRT < nd.tiles_y_local;
+    int t0 = 0;
+    if (lazy) {
+        const int xa = base < 0 ? 0 : (base >= n_src ? n_src - 1 : base), xe = base + span - 1, xb = xe < 0 ? 0 : (xe >= n_src ? n_src - 1 : xe);
+        const int ty = (row - nd.tile_row0) / RT_BLUE_NSQRT, nt = xb / RT_BLUE_NSQRT - xa / RT_BLUE_NSQRT + 1;
+        t0 = xa / RT_BLUE_NSQRT;
+        int mine = 0;
+        for (int k = threadIdx.x; k < nt; k += 256) {
+            const int tx = t0 + k;
+            const unsigned char v = tx < nd.tiles_x ? nd.need[tx * nd.tiles_y_local + ty] : (unsigned char)1;
+            s_need[k] = v;
+            mine |= v;
+        }
+        if (!__syncthreads_or(mine)) {
+            if (id < n_dst) dst[((size_t)pl * rows + row) * n_dst + id] = 0.0f;
+            return;
+        }
+    }
     if (staged)
         for (int j = threadIdx.x; j < span; j += 256) {
             int is = base + j, i = is;
             if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
-            s_src[RT_RS_IDX(j)] = s[i];
+            s_src[RT_RS_IDX(j)] = (lazy && !s_need[i / RT_BLUE_NSQRT - t0]) ? 0.0f : s[i];
         }
     if (utaps) {
         const double *p0 = T.taps + T.offset[0];
@@ -2003,7 +2033,7 @@ __global__ void __launch_bounds__(256) k_resample_rows(const float *src, int pla
         for (int k = 0; k < cnt; k++) {
             int is = i0 + k, i = is;
             if ((unsigned)is >= (unsigned)n_src) i = is < 0 ? 0 : n_src - 1;
-            double y = (double)s[i], fw = pf[k];
+            double y = need_unwritten(nd, i, row) ? 0.0 : (double)s[i], fw = pf[k];
             sum += fw * y;
             wsum += fw;
         }

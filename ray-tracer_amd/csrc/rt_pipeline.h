@@ -114,6 +114,8 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
        instead of from all over the tile.  Which sample a work item is changes, nothing else does: results are stored
        by sample index.  Null = trace in index order (chunks that do not start and end on tile boundaries). */
     const unsigned short *fb_order;
+    int     need_lazy;                  /* the passes behind the splat gather take the pixels of tiles with tile_need == 0 as zeros without reading
+                                           them (RtNeedMap::lazy): the gather does not write them */
     int     mask_skips_rgb;             /* the caller's reconstruction honours the mask: masked tiles' (black) sample colours are neither written nor read */
     double  size, adjust_x, adjust_y;   /* fSize, vAdjust, Sampling.cpp:490-496 */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */

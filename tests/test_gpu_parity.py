@@ -730,15 +730,17 @@ def test_tile_candidate_lists_are_invisible(gpu, scene):
                 assert np.array_equal(a, ref), (w, h, spp, mode)
                 assert sa.rays() == sr.rays() and sa.samples == sr.samples
             assert ref.max() > 0
-            # reconstruction's skip of what cannot matter (tile_need: 1 = the splat gather, 2 = the resampling passes too)
-            for mode in (0, 1):
+            # reconstruction's skip of what cannot matter (tile_need: 1 = the splat gather computes nothing there, 2 = the
+            # resampling passes skip destinations that read nothing else, 3 (default, what `ref` ran with) = the gather
+            # does not even write those pixels and the row pass takes them as zeros without loading them)
+            for mode in (0, 1, 2):
                 L.rt_set_option(b"tile_need", mode)
                 b, sb = g.render(w, h, spp, row0=r0, row1=r1)
                 assert np.array_equal(b, ref) and sb.rays() == sr.rays(), (w, h, spp, mode)
-            L.rt_set_option(b"tile_need", 2)
+            L.rt_set_option(b"tile_need", 3)
     finally:
         L.rt_set_option(b"tile_cand", 2)
-        L.rt_set_option(b"tile_need", 2)
+        L.rt_set_option(b"tile_need", 3)
 
 
 def test_single_candidate_shortcut_is_invisible(gpu):
