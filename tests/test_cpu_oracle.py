@@ -396,3 +396,36 @@ def test_laboratory_scene_script(rt, oracle):
     st = rt.RtStats()
     img, _, n = oracle.OracleScene(fs.desc).render(64, 36, 1, rt.RtRenderDesc(64, 36, 1.0, 0, 0), st, threads=4)
     assert np.isfinite(img).all() and img.mean() > 0.05 and st.rays() > 5 * n
+
+
+def test_host_spectrum_builders_against_their_formulas(rt):
+    """a16: the front end's BlackBody (RadiometryColor.cpp:985-1012) and RGBtoSpectrum (:947-969), evaluated here from the
+    formulas: Planck's law at the ten band wavelengths, scaled as the reference scales it, and the three-way decomposition of
+    an RGB triple into white plus two primaries (spectra from the extracted tables)."""
+    import ctypes as C
+    L = rt.frontend_lib()
+    fs = rt.FrontScene("(scene (model (material 0.9 auto (blackbody 6500) plastic none none (sphere))) (camera perspective 0 0 6 40))", "", optimize=False)
+    d = fs.desc.contents
+    mats = [i for i in range(d.n_nodes) if d.nodes[i].type == 12]
+    col = np.array([d.data[d.nodes[mats[0]].data + 2 + k] for k in range(10)])
+    h, c, kB = 6.62606876e-34, 2.99792458e+8, 1.3806503e-23
+    lam = 1e-9 * (380 + 40 * np.arange(10.0))
+    planck = 2 * np.pi * h * c * c / (lam ** 5 * (np.exp(h * c / kB / lam / 6500.0) - 1.0))
+    want = (planck / 30932027310080.0).astype(np.float32) / np.float32(12.0)
+    want = (want.astype(np.float64) * 1.98).astype(np.float32)
+    assert np.allclose(col, want, rtol=2e-6), (col, want)
+    # RGBtoSpectrum: red smallest -> white * r + green * (g - r) + blue * (b - r)
+    fs2 = rt.FrontScene("(scene (model (material 0.9 auto (rgb 0.2 0.5 0.9) plastic none none (sphere))) (camera perspective 0 0 6 40))", "", optimize=False)
+    d2 = fs2.desc.contents
+    m2 = [i for i in range(d2.n_nodes) if d2.nodes[i].type == 12][0]
+    got = np.array([d2.data[d2.nodes[m2].data + 2 + k] for k in range(10)])
+    def table(name):
+        f = rt.FrontScene("(scene (model (material 0.9 auto %s plastic none none (sphere))) (camera perspective 0 0 6 40))" % name, "", optimize=False)
+        dd = f.desc.contents
+        mm = [i for i in range(dd.n_nodes) if dd.nodes[i].type == 12][0]
+        return np.array([dd.data[dd.nodes[mm].data + 2 + k] for k in range(10)], dtype=np.float32)
+    W, G, B = table("g_sWhite"), table("g_sGreen"), table("g_sBlue")
+    r, g_, b = np.float32(0.2), np.float32(0.5), np.float32(0.9)
+    f32 = lambda spec, x: (spec.astype(np.float64) * float(x)).astype(np.float32)
+    want2 = f32(W, r) + f32(G, g_ - r) + f32(B, b - r)
+    assert np.allclose(got, want2, rtol=1e-6, atol=1e-7), (got, want2)

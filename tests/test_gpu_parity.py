@@ -348,6 +348,61 @@ def test_baseline_size_properties_S0_4k_64spp(gpu):
     assert torch.equal(c[:, 1080:1350, :], a[:, 1080:1350, :])
 
 
+def test_baseline_size_properties_S2_4k_256spp(gpu):
+    """BASELINE configs[2] (depth of field + glossy reflection through the blue-noise tile's lens and micro-facet
+    dimensions, 3840x2160 at 256 spp = 61440 x 34560 supersamples, 2,123,366,400 samples in several passes): sample-count
+    formula, shadow and reflection rays present, no overflow, finiteness, and a row band rendered on its own (the path a
+    rank of the 8-GPU run takes) equal to the same rows of the full frame."""
+    import torch
+    fs = gpu.FrontScene("S2", "", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    W, H = 3840, 2160
+    a = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+    st = g.render_device(W, H, 256, a.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert st.samples == 1536 * 864 * 1600 == 2123366400
+    assert st.rays_primary == st.samples and st.rays_shadow > st.samples // 4 and st.rays_secondary > st.samples // 50 and st.hit_overflow == 0
+    assert bool(torch.isfinite(a).all()) and float(a.sum()) > 0.0
+    c = torch.zeros_like(a)
+    g.render_device(W, H, 256, c.data_ptr(), 0, 1000, 1060)
+    torch.cuda.synchronize()
+    assert torch.equal(c[:, 1000:1060, :], a[:, 1000:1060, :])
+
+
+def test_baseline_size_mesh_10m_triangles(gpu, oracle):
+    """BASELINE configs[3] at its size: the 9,996,800-triangle closed mesh of bench.py's MESH10M (800 MB of triangles, 53 MB
+    of BVH nodes built on the host).  (1) A fan of rays against the oracle's brute force over all ten million triangles: hit
+    lists equal, so the quantised 4-wide BVH loses nothing at this depth.  (2) A frame with the mesh pre-walk (k_mesh_cross)
+    off and on: equal.  (3) The frame sees the mesh: shadow rays are cast from it."""
+    import bench
+    scene = bench.NAMED_SCENES["MESH10M"]
+    opt = gpu.FrontScene(scene, "fastblue", optimize=True)
+    raw = gpu.FrontScene(scene, "fastblue", optimize=False)
+    g = gpu.GpuScene(opt.desc)
+    o = oracle.OracleScene(raw.desc)
+    rng = np.random.default_rng(17)
+    n = 48
+    org = np.tile(np.array([0.0, 0.0, 6.0]), (n, 1))
+    dr = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), -np.ones(n)], 1)
+    org[n // 2:] = np.array([0.05, -0.1, 0.02])              # the second half starts inside the blob
+    dr[n // 2:] = rng.normal(0, 1, (n - n // 2, 3))
+    gr = g.intersect(org, dr, max_hits=20)
+    orr = o.intersect(org, dr, max_hits=20)
+    assert gr[0].max() >= 2 and (gr[0] > 0).mean() > 0.5
+    for x, y in zip(gr, orr):
+        assert np.array_equal(x, y)
+    frames = []
+    for on in (0, 1):
+        gpu.set_options({"mesh_pre": on})
+        gg = gpu.GpuScene(opt.desc)
+        img, st = gg.render(320, 180, 4)
+        assert st.hit_overflow == 0
+        frames.append((img, st.rays()))
+        gg.close()
+    assert frames[0][1] == frames[1][1] and np.array_equal(frames[0][0], frames[1][0])
+    assert frames[1][1] > 1.5 * 320 * 180 * 4
+
+
 def test_long_hit_lists_compact_the_arena(gpu, oracle):
     """26 hits per ray: the arena (64 records) only suffices because dead records left by merges are compacted."""
     opt, raw, g, o = _pair(gpu, oracle, SCENE_ROW, "")
