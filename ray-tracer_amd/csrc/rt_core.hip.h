@@ -774,6 +774,9 @@ struct MeshGlobalSink {
         }
     }
 };
+/* WALK = false (the LITE kernels of a scene whose rays are all pre-walked): a ray without pre-walked crossings (its walk ran
+   out of stack) is handed to the FULL kernel, which walks it in line */
+template <bool WALK>
 RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag, const SceneLds &L)
 {
     const RtMeshInfo mi = S.meshes[mp.plane0];
@@ -785,7 +788,8 @@ RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, con
     if (pre >= 0) {                     /* found by k_mesh_cross: the same walk, run in a kernel of its own */
         for (int i = 0; i < pre; i++) { K.ht[i] = L.mx_t[(size_t)i * L.mxcap + A.mesh_slot]; K.hq[i] = L.mx_q[(size_t)i * L.mxcap + A.mesh_slot]; }
         K.nh = pre;
-    } else if (!mesh_walk(S.mesh_nodes + mi.node0, tris, ray, L.mstack + threadIdx.x, L.stride, RT_MESH_STACK, K)) {
+    } else if constexpr (!WALK) { A.bail = 1; return; }
+    else if (!mesh_walk(S.mesh_nodes + mi.node0, tris, ray, L.mstack + threadIdx.x, L.stride, RT_MESH_STACK, K)) {
         A.overflow |= OVF_MESH_STACK;
     }
     double *const ht = K.ht;
@@ -1064,7 +1068,9 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
 /* TILES: the caller may pass the candidate list of a primary ray's sampling tile (k_tile_mask).  A template parameter, so
    that kernels for scenes and levels without such lists are compiled without that code: its few extra live registers
    cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
-template <bool LITE, bool CH_LDS = false, bool TILES = false>
+/* MESHPRE (LITE only): the scene's one mesh instruction is served from pre-walked crossings (k_mesh_cross ran over every ray
+   of the level before this kernel) instead of handing the ray over */
+template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
 {
@@ -1133,8 +1139,9 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             if constexpr (LITE) { A.bail = 1; goto done; }
             else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_MESH:
-            if constexpr (LITE) { A.bail = 1; goto done; }
-            else { PROF_BEGIN(tp); mesh_hits(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); PROF_END(A, 2, tp); break; }
+            if constexpr (LITE && !MESHPRE) { A.bail = 1; goto done; }
+            else if constexpr (LITE) { mesh_hits<false>(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); if (A.bail) goto done; break; }
+            else { PROF_BEGIN(tp); mesh_hits<true>(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -1241,9 +1248,16 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 case OP_POLY:    poly_hits(pr, (uint16_t)ch.prim, S.planes, r, A, in.tag, &ch); break;
                 case OP_SLAB:    slab_hits(pr, (uint16_t)ch.prim, r, A, in.tag, &ch); break;
                 default:
-                    if constexpr (LITE) { A.bail = 1; goto done; }
-                    else {
-                        if (ch.prim_op == OP_MESH) mesh_hits(S, pr, (uint16_t)ch.prim, r, A, in.tag, L);
+                    if constexpr (LITE && !MESHPRE) { A.bail = 1; goto done; }
+                    else if constexpr (LITE) {
+                        if (ch.prim_op != OP_MESH) { A.bail = 1; goto done; }
+                        mesh_hits<false>(S, pr, (uint16_t)ch.prim, r, A, in.tag, L);
+                        if (A.bail) goto done;
+                        if (A.nlist > before)
+                            for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
+                        break;
+                    } else {
+                        if (ch.prim_op == OP_MESH) mesh_hits<true>(S, pr, (uint16_t)ch.prim, r, A, in.tag, L);
                         else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }

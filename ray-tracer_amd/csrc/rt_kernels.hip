@@ -722,7 +722,7 @@ RT_DEV void shadow_append(const RtDevScene &S, const RtPipe &P, const D3 &Ppt, c
 /* The walk below is written out in this kernel (and again, as visual_walk, for k_fast): routed through the shared function
    the interpreter kernels spill 300 B more per lane and S1 / S2 render 6-7 % slower (same box, alternating: S2 483 against
    454 ms, S1 361 against 338).  Every parity test runs both copies against the oracle. */
-template <bool LITE, int MODE, bool TILES = false>
+template <bool LITE, int MODE, bool TILES = false, bool MESHPRE = false>
 __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
@@ -730,6 +730,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
     if constexpr (!LITE) if (f1 <= f0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }     /* slow list: k_mesh_cross went first */
+    if constexpr (LITE && MESHPRE) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
     /* LITE && TILES (the primary level of a pass with tile lists) with RT_BOUND_ON_DEVICE in n_chains_lds: [f0, f1) is an
@@ -797,7 +798,8 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                 if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
             }
         }
-        int count = intersect_scene<LITE, CH_LDS, TILES>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one, (!LITE && !direct) ? wbase + wlane : -1);
+        int count = intersect_scene<LITE, CH_LDS, TILES, MESHPRE>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one,
+                                                                  (LITE && MESHPRE) ? f - P.mx_f0 : ((!LITE && !direct) ? (P.mx_all ? f - P.mx_f0 : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
@@ -1175,11 +1177,14 @@ RT_DEV void mesh_cross_emit(const RtPipe &P, int *wave_nh, const int slot0, cons
         P.mx_q[(size_t)k * P.mxcap + slot0 + owner] = q;
     }
 }
+/* n_all < 0: over the slow list (entry = position in the list); n_all >= 0 (P.mx_all): over every ray of the level -- visual
+   frames f0 .. f0 + n_all (entry f - f0), or all the level's shadow rays (their count is on the device; entry = ray index) */
 template <bool SHADOW>
-__global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_cross(const RtDevScene S, RtPipe P)
+__global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_cross(const RtDevScene S, RtPipe P, int f0, int n_all)
 {
     extern __shared__ int mx_lds[];
-    const int n = P.counters[SHADOW ? CTR_SLOW_S : CTR_SLOW_V];
+    const bool all = n_all >= 0;
+    const int n = all ? (SHADOW ? P.counters[CTR_SNAP + 1] : n_all) : P.counters[SHADOW ? CTR_SLOW_S : CTR_SLOW_V];
     int *const work = &P.counters[SHADOW ? CTR_WORK_MS : CTR_WORK_MV];
     const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *const stack = mx_lds + threadIdx.x;                        /* entry i at [i * RT_MESHPRE_THREADS] */
@@ -1199,8 +1204,8 @@ __global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_c
         DRay ray;
         ray.org = d3(0.0, 0.0, 0.0); ray.dir = d3(0.0, 0.0, 1.0);
         if (live) {
-            if (SHADOW) { const int s = P.slow_s[slot]; ray.org = d3_fetch(P.s_ray, P.scap, 0, s); ray.dir = d3_fetch(P.s_ray, P.scap, 3, s); }
-            else { const int f = P.slow_v[slot]; ray.org = d3_fetch(P.f_ray, P.fcap, 0, f); ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f); }
+            if (SHADOW) { const int s = all ? slot : P.slow_s[slot]; ray.org = d3_fetch(P.s_ray, P.scap, 0, s); ray.dir = d3_fetch(P.s_ray, P.scap, 3, s); }
+            else { const int f = all ? f0 + slot : P.slow_v[slot]; ray.org = d3_fetch(P.f_ray, P.fcap, 0, f); ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f); }
             for (int k = 0; k < S.mesh_pre_naff; k++) {                 /* AffineSolid::Intersect (Solids.cpp:899-913), as OP_PUSH_AFFINE does it */
                 const RtAffine &a = S.affines[S.mesh_pre_aff[k]];
                 DRay nr;
@@ -1320,10 +1325,10 @@ __global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_c
     }
 #undef MSTK
 }
-template __global__ void k_mesh_cross<false>(const RtDevScene, RtPipe);
-template __global__ void k_mesh_cross<true>(const RtDevScene, RtPipe);
+template __global__ void k_mesh_cross<false>(const RtDevScene, RtPipe, int, int);
+template __global__ void k_mesh_cross<true>(const RtDevScene, RtPipe, int, int);
 
-template <bool LITE, int MODE>
+template <bool LITE, int MODE, bool MESHPRE = false>
 __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
@@ -1331,6 +1336,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
     if constexpr (!LITE) if (nrays == 0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }       /* slow list: k_mesh_cross went first */
+    if constexpr (LITE && MESHPRE) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }
     const bool slow_list = !LITE && nrays == 0;     /* FULL: nrays == 0 = the slow list of the LITE launch before it */
     if (nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
     const bool direct = !slow_list;
@@ -1365,7 +1371,8 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
         Arena A;
         int start;
-        int count = intersect_scene<LITE, CH_LDS>(S, lds, ray, 1.0, A, start, 0, 0, -1, (!LITE && !direct) ? wbase + wlane : -1);
+        int count = intersect_scene<LITE, CH_LDS, false, MESHPRE>(S, lds, ray, 1.0, A, start, 0, 0, -1,
+                                                                  (LITE && MESHPRE) ? s : ((!LITE && !direct) ? (P.mx_all ? s : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
         int i = 0, pm = 0;

@@ -71,7 +71,11 @@ typedef struct RtPipe {
        of stack, walk again in line), unsorted, crossing i at [i * mxcap + k]: distance and position in mesh_tris.  Written by
        k_mesh_cross between the LITE and the FULL launch, for the visual rays and then again for the shadow rays of a level. */
     int    *mx_n; double *mx_t; int *mx_q;
-    int     mxcap, pad2_;
+    int     mxcap;
+    int     mx_all;             /* 1: k_mesh_cross ran over EVERY ray of the level before the LITE kernels (which then read the crossings
+                                   themselves): a visual ray's record is entry f - mx_f0, a shadow ray's its own index; 0: entry = position
+                                   in the slow list */
+    int     mx_f0, pad3_;
     /* the sampling tiles' candidate lists (RtSampleGrid::tile_mask / tile_cand) for the PRIMARY rays of this chunk: root
        sample k of the chunk lies in tile (tile_first + k) / 1600.  Null = none. */
     const unsigned char  *tile_n;

@@ -392,7 +392,7 @@ def test_baseline_size_mesh_10m_triangles(gpu, oracle):
     for x, y in zip(gr, orr):
         assert np.array_equal(x, y)
     frames = []
-    for on in (0, 1):
+    for on in (0, 2):
         gpu.set_options({"mesh_pre": on})
         gg = gpu.GpuScene(opt.desc)
         img, st = gg.render(320, 180, 4)
@@ -665,17 +665,17 @@ def test_mesh_pre_walk_is_invisible(gpu, oracle, wrap):
     secondary rays start on and inside it."""
     scene = ONE_MESH if wrap == "plain" else ONE_MESH.replace("(material 0.9 auto g_sOrange plastic none none (surface shiny none", "(material 0.9 1.5 g_sWhite transparent none none (surface polished none")
     out = []
-    for on in (0, 1):
+    for on in (0, 1, 2):        # off; over the slow lists, for the FULL kernels; over every ray, for the LITE kernels too (default)
         gpu.set_options({"mesh_pre": on})
         fs = gpu.FrontScene(scene, "fastblue", optimize=True)
         img, st = gpu.GpuScene(fs.desc).render(160, 90, 4)
         assert st.hit_overflow == 0
         out.append((img, (st.rays_primary, st.rays_shadow, st.rays_secondary)))
-    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] == out[2][1] and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
     raw = gpu.FrontScene(scene, "fastblue", optimize=False)
     ost = gpu.RtStats()
     ref, _, n = oracle.OracleScene(raw.desc).render(160, 90, 4, gpu.RtRenderDesc(160, 90, 4.0, 0, 0), ost, threads=16)
-    assert out[1][1] == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary) and np.array_equal(out[1][0], ref)
+    assert out[2][1] == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary) and np.array_equal(out[2][0], ref)
 
 
 def test_mesh_keeps_the_nearest_sixteen_crossings(gpu, oracle):
