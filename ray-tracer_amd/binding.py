@@ -250,6 +250,11 @@ def get_options():
     return {n: int(L.rt_get_option(n.encode())) for n in OPTION_NAMES}
 
 
+def direct_launches():
+    """FULL kernels launched without a LITE launch before them since the library was loaded (option direct_full; read-only)."""
+    return int(rt_lib().rt_get_option(b"direct_launches"))
+
+
 def set_options(opts):
     L = rt_lib()
     for n, v in opts.items():

@@ -717,6 +717,28 @@ def test_laboratory_frames_match_oracle(gpu, oracle, name):
     assert _rel_rmse(img, ref) <= 1e-5 and np.abs(img - ref).max() <= 1e-2
 
 
+def test_direct_full_launches_are_invisible(gpu):
+    """Option direct_full: a level whose rays the LITE kernels mostly handed over the last time the same chunk was rendered
+    goes to the FULL kernels at once.  S4 (glass with tori and spectral metals: its deeper levels hand over 80-95 %): the
+    second and third render of a scene take the direct launches (counted by the library), and image and ray counts are
+    those of a render with the option off."""
+    fs = gpu.FrontScene("S4", "fastblue", optimize=True)
+    gpu.set_options({"direct_full": 0})
+    try:
+        ref, rst = gpu.GpuScene(fs.desc).render(256, 144, 4)
+    finally:
+        gpu.set_options({"direct_full": 1})
+    g = gpu.GpuScene(fs.desc)
+    n0 = gpu.direct_launches()
+    seen = []
+    for k in range(3):
+        img, st = g.render(256, 144, 4)
+        seen.append(gpu.direct_launches())
+        assert np.array_equal(img, ref), k
+        assert (st.rays_primary, st.rays_shadow, st.rays_secondary, st.hit_overflow) == (rst.rays_primary, rst.rays_shadow, rst.rays_secondary, 0), k
+    assert seen[1] > seen[0] >= n0 and seen[2] > seen[1]       # from the second render on, the chunk's own memory decides
+
+
 SCENE_TINY = """(scene (model %s)
  (ambient (scale (blackbody 6500) 0.05)) %s
  (camera perspective 0 0 6 40) (sampler fastblue))"""
