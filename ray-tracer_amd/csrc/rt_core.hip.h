@@ -649,7 +649,8 @@ RT_DEV bool mesh_triangle(const RtMeshTri &T, const DRay &ray, double &t)
     return t >= 0.0;
 }
 #ifdef RT_MESH_COUNT        /* instrumentation build (RT_EXTRA_DEFS=-DRT_MESH_COUNT): [0] rays, [1] node visits, [2] leaf visits, [3] triangle tests, [4] wave-iterations of the node loop, [5] of the leaf loop */
-__device__ unsigned long long g_mesh_count[8];
+__device__ unsigned long long g_mesh_count[32];     /* [8..15] FULL, [16..23] LITE interpreter loop: +0 wave iterations, +1 distinct opcodes summed over them, +2 active lanes summed over them, +3 rays, +4 lane iterations */
+__device__ unsigned long long g_op_time[32], g_op_rounds[32], g_op_lanes[32];      /* SCHED interpreter: per opcode, clock ticks / rounds / lanes of the rounds it led */
 #define MESH_COUNT(k, v) atomicAdd(&g_mesh_count[k], (unsigned long long)(v))
 #define MESH_WAVE_COUNT(k) do { if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_mesh_count[k], 1ull); } while (0)
 #else
@@ -1070,7 +1071,15 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
 /* MESHPRE (LITE only): the scene's one mesh instruction is served from pre-walked crossings (k_mesh_cross ran over every ray
    of the level before this kernel) instead of handing the ray over */
-template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false>
+/* scheduling classes of the opcodes (3 bits each, FULL kernels): 0 control flow and frames, 1 relabelling, 2 merges, 3 end of a
+   region child (its folds), 4 region entry (BVH walk), 5 bare primitives, 6 chains, 7 tori and meshes */
+#define RT_SCHED_CLS(op, c) ((unsigned long long)(c) << (3 * (op)))
+#define RT_SCHED_CLASSES (RT_SCHED_CLS(OP_END, 0) | RT_SCHED_CLS(OP_BOUND, 0) | RT_SCHED_CLS(OP_REFBOX, 0) | RT_SCHED_CLS(OP_PUSH_AFFINE, 0) | RT_SCHED_CLS(OP_POP_AFFINE, 0) | \
+                          RT_SCHED_CLS(OP_SKIP_EMPTY, 0) | RT_SCHED_CLS(OP_RETAG, 1) | RT_SCHED_CLS(OP_MATERIAL, 1) | RT_SCHED_CLS(OP_SURFACE, 1) | \
+                          RT_SCHED_CLS(OP_UNION, 2) | RT_SCHED_CLS(OP_INTER, 2) | RT_SCHED_CLS(OP_DIFF, 2) | RT_SCHED_CLS(OP_ANGCLIP, 2) | RT_SCHED_CLS(OP_RET, 3) | \
+                          RT_SCHED_CLS(OP_REGION, 4) | RT_SCHED_CLS(OP_QUADRIC, 5) | RT_SCHED_CLS(OP_POLY, 5) | RT_SCHED_CLS(OP_SLAB, 5) | RT_SCHED_CLS(OP_CHAIN, 6) | \
+                          RT_SCHED_CLS(OP_TORUS, 7) | RT_SCHED_CLS(OP_MESH, 7))
+template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false, bool SCHED = false>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
 {
@@ -1094,6 +1103,11 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     A.prof[7] = (int)(clock64() - t_cr);
 #endif
     int pc = 0;
+    RtInstr in;
+    bool fetch = true;     /* (SCHED) this lane ran its instruction in the round before */
+#ifdef RT_MESH_COUNT
+    long long cnt_t0 = 0; int cnt_op = 0;
+#endif
     if (TILES && S.n_root_alt > 0 && (tile_one >= 0 || (tile_list && tile_n == 1))) {
         /* the sampling tile of this primary ray can touch ONE child of the root region: if that is a bare chain, its
            box is tested here and the chain runs alone, for the root consumer (what the region would have made of it).
@@ -1106,9 +1120,49 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             pc = apc;
         }
     }
+#ifdef RT_MESH_COUNT
+    MESH_COUNT(LITE ? 19 : 11, 1);
+#endif
     for (;;) {
-        const RtInstr in = S.prog[pc];
-        pc++;
+        if (!SCHED || fetch) { in = S.prog[pc]; pc++; }
+#ifdef RT_MESH_COUNT
+        if constexpr (SCHED) {
+            if (fetch && cnt_t0) {          /* the round before: charged to the opcode of the first lane that ran in it */
+                const unsigned long long ran = __ballot(1);
+                if ((__ffsll((long long)ran) - 1) == (int)(threadIdx.x & 63)) {
+                    atomicAdd(&g_op_time[cnt_op], (unsigned long long)(clock64() - cnt_t0)); atomicAdd(&g_op_rounds[cnt_op], 1ull); atomicAdd(&g_op_lanes[cnt_op], (unsigned long long)__popcll(ran));
+                }
+            }
+        }
+#endif
+        if constexpr (SCHED) {
+            /* the lanes of a wave sit at different instructions: instead of running every opcode present one after the other
+               with a handful of lanes each, a round runs ONE class of opcodes -- the cheapest present -- and the other lanes
+               wait, so that they gather at the expensive instructions (primitives, merges) and run those together.  A lane
+               still executes its own instructions in its own order: results do not depend on this */
+            const int cls = (int)((RT_SCHED_CLASSES >> (3 * in.op)) & 7ull);
+            fetch = true;
+            if (__ballot(cls != __builtin_amdgcn_readfirstlane(cls))) {        /* (a wave of like rays skips all this) */
+                int run = 0;
+                while (!__ballot(cls == run)) run++;
+                fetch = cls == run;
+                if (!fetch) continue;
+            }
+        }
+#ifdef RT_MESH_COUNT
+        cnt_t0 = clock64(); cnt_op = in.op;
+        {
+            const unsigned long long act = __ballot(1);
+            unsigned long long rest = act;
+            int nd = 0;
+            const int op = in.op;
+            while (rest) { const int o = __shfl(op, __ffsll((long long)rest) - 1); rest &= ~__ballot(op == o); nd++; }
+            if ((__ffsll((long long)act) - 1) == (int)(threadIdx.x & 63)) {
+                const int b = LITE ? 16 : 8;
+                atomicAdd(&g_mesh_count[b], 1ull); atomicAdd(&g_mesh_count[b + 1], (unsigned long long)nd); atomicAdd(&g_mesh_count[b + 2], (unsigned long long)__popcll(act));
+            }
+        }
+#endif
         switch (in.op) {
         case OP_END:
             goto done;
@@ -1172,21 +1226,21 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         case OP_UNION: {                                        /* Union::Intersect, Solids.cpp:1060-1075 */
             bool r = top_is(A, 2 * in.b + 1);
             bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
-            if (l && r) merge_top(A, MERGE_MAX, S.mats, in.tag);
+            if (l && r) { PROF_BEGIN(tm); merge_top(A, MERGE_MAX, S.mats, in.tag); PROF_END(A, 9, tm); }
             else if (l || r) list_retag_top(A, in.tag);
             break;
         }
         case OP_INTER: {                                        /* Intersection::Intersect, Solids.cpp:1139-1158 */
             bool r = top_is(A, 2 * in.b + 1);
             bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
-            if (l && r) merge_top(A, MERGE_MIN, S.mats, in.tag);
+            if (l && r) { PROF_BEGIN(tm); merge_top(A, MERGE_MIN, S.mats, in.tag); PROF_END(A, 9, tm); }
             else if (l || r) drop_top(A);
             break;
         }
         case OP_DIFF: {                                         /* Difference::Intersect, Solids.cpp:1177-1196 */
             bool r = top_is(A, 2 * in.b + 1);
             bool l = r ? second_is(A, 2 * in.b) : top_is(A, 2 * in.b);
-            if (l && r) merge_top(A, MERGE_DIFF, S.mats, in.tag);
+            if (l && r) { PROF_BEGIN(tm); merge_top(A, MERGE_DIFF, S.mats, in.tag); PROF_END(A, 9, tm); }
             else if (l) list_retag_top(A, in.tag);
             else if (r) drop_top(A);
             break;

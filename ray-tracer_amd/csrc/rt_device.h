@@ -243,6 +243,7 @@ typedef struct RtDevScene {
     /* the mesh pre-walk (k_mesh_cross): the program holds exactly ONE mesh instruction, reached through the affines
        mesh_pre_aff[0 .. mesh_pre_naff) (outermost first) and, when the mesh is a chain's primitive, that chain's own affine;
        mesh_pre_naff < 0 = no pre-walk (no mesh, or more than one) */
-    int32_t           mesh_pre_naff, mesh_pre_chain, mesh_pre_mesh, pad2_;
+    int32_t           mesh_pre_naff, mesh_pre_chain, mesh_pre_mesh;
+    int32_t           sched;                /* the scene runs the FULL kernels whose interpreter takes one class of opcodes per round (intersect_scene, SCHED): long programs, whose rays sit at different instructions */
     int32_t           mesh_pre_aff[RT_MAX_AFFINE_DEPTH];
 } RtDevScene;

@@ -525,8 +525,11 @@ __global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
 /* FULL kernels come in two register budgets.  MODE 0 (default): 256 registers = two waves per SIMD (two workgroups of
    256 per CU): mesh walks wait on memory and run 1.4x faster with a second wave to switch to; S2 458 ms against 472,
    S1 the same.  MODE -1 (option full_waves = 1): the whole register file, one wave per SIMD, no spills. */
-#define RT_LB_VISUAL(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_VISUAL_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : 2)
-#define RT_LB_SHADOW(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_SHADOW_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : 2)
+#ifndef RT_FULL_PER_CU
+#define RT_FULL_PER_CU 2
+#endif
+#define RT_LB_VISUAL(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_VISUAL_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : RT_FULL_PER_CU)
+#define RT_LB_SHADOW(LITE, MODE) __launch_bounds__((LITE) ? RT_LITE_SHADOW_THREADS : 256, ((LITE) || (MODE) < 0) ? 1 : RT_FULL_PER_CU)
 #endif
 /* ------------------------------------------------------------------ k_visual
  * RayTracer::VisualRay (Shade.cpp:401-520) up to the light loop, for frames [f0, f1).
@@ -722,7 +725,9 @@ RT_DEV void shadow_append(const RtDevScene &S, const RtPipe &P, const D3 &Ppt, c
 /* The walk below is written out in this kernel (and again, as visual_walk, for k_fast): routed through the shared function
    the interpreter kernels spill 300 B more per lane and S1 / S2 render 6-7 % slower (same box, alternating: S2 483 against
    454 ms, S1 361 against 338).  Every parity test runs both copies against the oracle. */
-template <bool LITE, int MODE, bool TILES = false, bool MESHPRE = false>
+/* ALT: the LITE kernels' MESHPRE (the scene's mesh is served from pre-walked crossings), the FULL kernels' SCHED (intersect_scene
+   runs one class of opcodes per round) */
+template <bool LITE, int MODE, bool TILES = false, bool ALT = false>
 __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P, int f0, int f1, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
@@ -730,6 +735,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
     SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
     if constexpr (!LITE) if (f1 <= f0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }     /* slow list: k_mesh_cross went first */
+    constexpr bool MESHPRE = LITE && ALT, SCHED = !LITE && ALT;
     if constexpr (LITE && MESHPRE) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }
     /* persistent waves: every wave claims 64 consecutive frames at a time until none are left, so the tables staged
        in LDS serve the whole launch and a workgroup never idles behind its slowest wave */
@@ -798,12 +804,13 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                 if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
             }
         }
-        int count = intersect_scene<LITE, CH_LDS, TILES, MESHPRE>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one,
+        int count = intersect_scene<LITE, CH_LDS, TILES, MESHPRE, SCHED>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one,
                                                                   (LITE && MESHPRE) ? f - P.mx_f0 : ((!LITE && !direct) ? (P.mx_all ? f - P.mx_f0 : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
 #ifdef RT_PHASE_PROF
         for (int q = 1; q < 8; q++) prof_v[q] = A.prof[q];
+        prof_v[9] = A.prof[9];
         prof_v[8] = (int)(clock64() - prof_t0);
 #endif
         /* Shade.cpp:424-432: regularise into (0, t, ...) */
@@ -926,7 +933,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
 #ifdef RT_PHASE_PROF
     prof_v[0] = (int)(clock64() - prof_t0);
-    for (int q = 0; q < 9; q++) {           /* per-wave maxima, in units of 1024 cycles (int counters: 16 overflowed on long frames) */
+    for (int q = 0; q < 10; q++) {          /* per-wave maxima, in units of 1024 cycles (int counters: 16 overflowed on long frames) */
         int v = prof_v[q];
         for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
         if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[CTR_PROF + q], v >> 10);
@@ -1328,7 +1335,7 @@ __global__ void __launch_bounds__(RT_MESHPRE_THREADS, RT_MESHPRE_WAVES) k_mesh_c
 template __global__ void k_mesh_cross<false>(const RtDevScene, RtPipe, int, int);
 template __global__ void k_mesh_cross<true>(const RtDevScene, RtPipe, int, int);
 
-template <bool LITE, int MODE, bool MESHPRE = false>
+template <bool LITE, int MODE, bool ALT = false>
 __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P, int nrays, int n_chains_lds)
 {
     constexpr bool CH_LDS = MODE >= 1;
@@ -1336,6 +1343,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
     SceneLds lds = scene_lds_load(Sv, n_chains_lds, MODE == 2 ? &SL : 0);
     const RtDevScene &S = SL;
     if constexpr (!LITE) if (nrays == 0) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }       /* slow list: k_mesh_cross went first */
+    constexpr bool MESHPRE = LITE && ALT, SCHED = !LITE && ALT;
     if constexpr (LITE && MESHPRE) { lds.mx_n = P.mx_n; lds.mx_t = P.mx_t; lds.mx_q = P.mx_q; lds.mxcap = P.mxcap; }
     const bool slow_list = !LITE && nrays == 0;     /* FULL: nrays == 0 = the slow list of the LITE launch before it */
     if (nrays < 0) nrays = P.counters[CTR_SNAP + 1];     /* the level's shadow rays, frozen by k_level_snap: no host round trip */
@@ -1371,7 +1379,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
         Arena A;
         int start;
-        int count = intersect_scene<LITE, CH_LDS, false, MESHPRE>(S, lds, ray, 1.0, A, start, 0, 0, -1,
+        int count = intersect_scene<LITE, CH_LDS, false, MESHPRE, SCHED>(S, lds, ray, 1.0, A, start, 0, 0, -1,
                                                                   (LITE && MESHPRE) ? s : ((!LITE && !direct) ? (P.mx_all ? s : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;

@@ -739,6 +739,23 @@ def test_direct_full_launches_are_invisible(gpu):
     assert seen[1] > seen[0] >= n0 and seen[2] > seen[1]       # from the second render on, the chunk's own memory decides
 
 
+def test_scheduled_interpreter_is_invisible(gpu):
+    """Option sched: the FULL kernels of a scene with a long program run one class of opcodes per round (lanes wait for
+    each other at the expensive instructions).  Every lane still executes its own instructions in its own order: image and
+    ray counts of S4 (561 instructions: on by default) and S1 (60: off by default) do not depend on it."""
+    for name in ("S4", "S1"):
+        fs = gpu.FrontScene(name, "fastblue", optimize=True)
+        out = []
+        try:
+            for on in (0, 1):
+                gpu.set_options({"sched": on})
+                img, st = gpu.GpuScene(fs.desc).render(192, 108, 4)
+                out.append((img, (st.rays_primary, st.rays_shadow, st.rays_secondary, st.hit_overflow)))
+        finally:
+            gpu.set_options({"sched": 2})
+        assert out[0][1] == out[1][1] and out[0][1][3] == 0 and np.array_equal(out[0][0], out[1][0]), name
+
+
 SCENE_TINY = """(scene (model %s)
  (ambient (scale (blackbody 6500) 0.05)) %s
  (camera perspective 0 0 6 40) (sampler fastblue))"""
