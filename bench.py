@@ -193,11 +193,8 @@ def main():
             "sec_per_frame": dt / args.steps,
         }
         res["roofline"] = roofline(rt, gs, fs, W, H, spp, st, args.steps, rays_fast, res["config"]["workload"])
-        if scene_name.startswith("MESH"):
-            res["roofline"]["note"] = ("mesh workload: most of the GPU time is the mesh walk inside the FULL k_shadow / k_visual launches, "
-                                       "latency-bound on divergent 128-byte BVH node and 80-byte triangle reads (about 15 nodes + 11 triangles = "
-                                       "2.8 KB per mesh ray, tools/mesh_count.py); the figures in this object are the frame-record bytes of the "
-                                       "timed k_visual launches only")
+        if scene_name in MESH_WALK_BYTES:
+            res["roofline"] = mesh_roofline(rt, gs, scene_name, res["roofline"])
         note("roofline probe done")
         if not args.no_cpu_baseline:
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_baseline(ge, rt, args.scene, scene_name)
@@ -279,6 +276,32 @@ def frames_mode(args, rt, torch, dist, world, rank, rehearse):
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+# SURVEY 8d's unit for the mesh workload: visited BVH nodes x node bytes + tested triangles x triangle bytes per ray, counted by
+# the device on the BVH it walks (instrumented build, tools/mesh_count.py, 960x540 4 spp of the same scene: every ray of the
+# scene is walked through the mesh): 15.6 nodes of 64 B and 7.8 triangles of 80 B, plus the 48-byte ray the walk reads
+MESH_WALK_BYTES = {"MESH10M": 15.6 * 64.0 + 7.8 * 80.0 + 48.0}
+
+
+def mesh_roofline(rt, gs, name, other):
+    """Mesh workloads: the dominant kernel is k_mesh_cross (every ray of a level walked through the mesh's BVH before the
+    tracing kernels run), HBM-bound in SURVEY 8d's terms.  Durations: HIP events around its launches inside the timed region."""
+    L = rt.rt_lib()
+    L.rt_probe_mesh_time.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    t = np.zeros(3, dtype=np.float64)
+    L.rt_probe_mesh_time(gs.h, t.ctypes.data_as(C.POINTER(C.c_double)))
+    ms, launches, rays = t
+    if launches <= 0 or rays <= 0:
+        return dict(other, note="no k_mesh_cross launch was timed (option mesh_pre < 2?): figures of the tracing kernel")
+    b = MESH_WALK_BYTES[name]
+    gbs = b * rays / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_mesh_cross", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": None, "bytes_per_ray": b, "rays_per_launch": rays / launches, "ms_per_launch": ms / launches,
+            "in_kernel_rays_per_s": rays / (ms * 1e-3), "launches_timed": launches,
+            "note": "bytes_per_ray = 15.6 BVH nodes x 64 B + 7.8 triangles x 80 B + 48 B ray (device counts, tools/mesh_count.py); "
+                    "the walk is bound by memory-level parallelism (dependent node reads), not by bandwidth: DESIGN.md section 6",
+            "tracing_kernel": {k: other.get(k) for k in ("kernel", "achieved", "frac", "bytes_per_ray", "rays_per_launch", "ms_per_launch")}}
 
 
 def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):

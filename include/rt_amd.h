@@ -126,6 +126,9 @@ int  rt_probe_work(rt_scene *s, int n, const double *org3, const double *dir3, d
    render stream) and out2[1] = number of the k_fast launches made since the previous call while option "time_kernels" was 1.
    k_fast traces the primary rays that can only touch bare chains of the root union region (RtStats.rays_fast of them). */
 int  rt_probe_fast_time(rt_scene *s, double *out2);
+/* Same for the k_mesh_cross launches that walk every ray of a level through the scene's mesh (option mesh_pre = 2):
+   out3[0] = total ms, out3[1] = launches, out3[2] = rays walked. */
+int  rt_probe_mesh_time(rt_scene *s, double *out3);
 
 /* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 33,552,000 = 20970 sampling tiles; the queues of a pass take about 2 KB of HBM per sample),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),

@@ -203,12 +203,40 @@ RT_DEV void hit_add_tex(HitRec &h, int tex) { if (tex >= 0 && h.ntex < RT_MAX_TE
 
 /* which dynamic limit a ray ran into (Arena::overflow, reported in the error text) */
 enum { OVF_ARENA = 1, OVF_LISTS = 2, OVF_REGIONS = 4, OVF_CAND = 8, OVF_BVH_STACK = 16, OVF_MESH_STACK = 32 };
-struct Arena {              /* private (scratch) memory: lane-interleaved, uniform indices coalesce */
+/* Where a ray's hit records live.  POOL = false: private (scratch) memory -- lane-interleaved by the hardware, so lanes
+   that use the same index coalesce: right for waves of like rays (every kernel but the one below).  POOL = true: the lane's
+   own RT_ARENA contiguous records of a pool in global memory (RtPipe::arena_pool): right for the scheduled FULL kernels of
+   deep CSG scenes, where a handful of lanes are active at a time -- a 48-byte record of one lane is then one or two 64-byte
+   sectors instead of twelve dwords in twelve different 256-byte rows of the wave's scratch (S4 wrote 17 KB per ray through
+   the fabric that way). */
+template <bool POOL> struct ArenaStore {
     HitRec   h[RT_ARENA];
     uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
     int32_t  l_tag[RT_LIST_STACK];
     int32_t  l_gap[RT_LIST_STACK];      /* union regions: LCA depth between this entry and the one below it */
     uint16_t l_idx[RT_LIST_STACK];      /* union regions: last region child merged into this entry */
+};
+/* bytes of a lane's part of the pool: hit records, the list stack, then the interpreter's own arrays (WalkStore) */
+#define RT_POOL_LISTS   (RT_ARENA * 48)
+#define RT_POOL_WALK    (RT_POOL_LISTS + RT_LIST_STACK * 14 + 48)
+#define RT_POOL_STRIDE  ((RT_POOL_WALK + (RT_MAX_AFFINE_DEPTH + 1) * 48 + RT_MAX_REGION_DEPTH * (13 * 4 + RT_MAX_CAND * 2) + 63) / 64 * 64)
+template <> struct ArenaStore<true> {
+    HitRec   *h;
+    uint16_t *l_start, *l_count, *l_idx;
+    int32_t  *l_tag, *l_gap;
+    char     *walk;
+    RT_DEV void bind(void *pool, size_t lane)
+    {
+        char *p = (char *)pool + lane * RT_POOL_STRIDE;
+        h = (HitRec *)p;
+        l_tag = (int32_t *)(p + RT_POOL_LISTS); l_gap = l_tag + RT_LIST_STACK;
+        l_start = (uint16_t *)(l_gap + RT_LIST_STACK); l_count = l_start + RT_LIST_STACK; l_idx = l_count + RT_LIST_STACK;
+        walk = p + RT_POOL_WALK;
+    }
+};
+template <bool POOL>
+struct ArenaT : ArenaStore<POOL> {
+    static constexpr bool pool = POOL;
     int      nlist;
     int      t_start, t_count, t_tag;   /* register mirror of the top list entry (valid when nlist > 0): avoids store -> load round trips */
     int      top;           /* first free hit slot */
@@ -219,6 +247,7 @@ struct Arena {              /* private (scratch) memory: lane-interleaved, unifo
     int      prof[12];      /* cycles: [1] BVH candidate search, [2] primitive tests, [3] whole intersect, [4] chain setup, [5] wrappers, [6] region fold, [7] cull_ray */
 #endif
 };
+typedef ArenaT<false> Arena;
 #ifdef RT_PHASE_PROF
 #define PROF_BEGIN(v)      long long v = clock64()
 #define PROF_END(A, k, v)  (A).prof[k] += (int)(clock64() - v)
@@ -242,22 +271,22 @@ struct Work {
    synthetic hit it has just set), so only the scalars are initialised: the arrays live in private memory */
 RT_DEV void work_init(Work &w) { w.count = 0; w.inside_inf = 0; w.eps = RT_EPSILON; }
 
-__device__ void arena_compact(Arena &A);
-RT_DEV void list_push(Arena &A, int start, int count, int tag)
+template <class AR> __device__ void arena_compact(AR &A);
+template <class AR> RT_DEV void list_push(AR &A, int start, int count, int tag)
 {
     A.l_start[A.nlist] = (uint16_t)start; A.l_count[A.nlist] = (uint16_t)count; A.l_tag[A.nlist] = tag;
     A.t_start = start; A.t_count = count; A.t_tag = tag;
     A.nlist++;
 }
-RT_DEV void list_reload_top(Arena &A)
+template <class AR> RT_DEV void list_reload_top(AR &A)
 {
     if (A.nlist > 0) { A.t_start = A.l_start[A.nlist - 1]; A.t_count = A.l_count[A.nlist - 1]; A.t_tag = A.l_tag[A.nlist - 1]; }
 }
-RT_DEV void list_retag_top(Arena &A, int tag) { A.l_tag[A.nlist - 1] = tag; A.t_tag = tag; }
+template <class AR> RT_DEV void list_retag_top(AR &A, int tag) { A.l_tag[A.nlist - 1] = tag; A.t_tag = tag; }
 
 /* HitWork::HitList, Solids.cpp:172-227 -> pushes a new list (if not empty) for consumer `tag` */
-template <class W>
-__device__ void hit_list(W &w, Arena &A, int tag, uint16_t prim, int leaf_affine)
+template <class W, class AR>
+__device__ void hit_list(W &w, AR &A, int tag, uint16_t prim, int leaf_affine)
 {
     int first, origin_inside;
     for (first = 0; first < w.count; first++)
@@ -322,8 +351,9 @@ RT_DEV void hit_apply_wraps(const RtChain &ch, HitRec &h)
 #else
 #define HSTORE(dst, src) (dst) = (src)
 #endif
+template <class AR>
 struct ArenaEmit {
-    Arena &A; int tag;
+    AR &A; int tag;
     RT_DEV bool begin(int L)
     {
         if (A.top + L > RT_ARENA) arena_compact(A);
@@ -403,9 +433,10 @@ RT_DEV void hit_list2_core(Work &w, Emit &out, uint16_t prim, int leaf_affine, c
     }
     out.end(L);
 }
-__device__ void hit_list2(Work &w, Arena &A, int tag, uint16_t prim, int leaf_affine, const RtChain *ch = 0)
+template <class AR>
+__device__ void hit_list2(Work &w, AR &A, int tag, uint16_t prim, int leaf_affine, const RtChain *ch = 0)
 {
-    ArenaEmit out = { A, tag };
+    ArenaEmit<AR> out = { A, tag };
     hit_list2_core(w, out, prim, leaf_affine, ch);
 }
 
@@ -545,26 +576,30 @@ RT_DEV void slab_roots(const DRay &ray, Work &w)        /* Solids.cpp:859-869 */
     int n = clip_plane(ray, d3(0.0, 0.0, 1.0), w, 0, 1.0);
     if (n) n = clip_plane(ray, d3(0.0, 0.0, -1.0), w, 1, 1.0);
 }
-__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+template <class AR>
+__device__ void quadric_hits(const RtPrim &q, uint16_t prim, const DRay &ray, AR &A, int tag, const RtChain *ch = 0)
 {
     Work w;
     quadric_roots(q.p[0], q.p[1], q.p[2], q.i0, ray, w);
     hit_list2(w, A, tag, prim, q.leaf_affine, ch);
 }
-__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+template <class AR>
+__device__ void poly_hits(const RtPrim &p, uint16_t prim, const double *planes, const DRay &ray, AR &A, int tag, const RtChain *ch = 0)
 {
     Work w;
     poly_roots(planes + 3 * (size_t)p.plane0, p.i0, ray, w);
     hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
-__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, Arena &A, int tag, const RtChain *ch = 0)
+template <class AR>
+__device__ void slab_hits(const RtPrim &p, uint16_t prim, const DRay &ray, AR &A, int tag, const RtChain *ch = 0)
 {
     Work w;
     slab_roots(ray, w);
     hit_list2(w, A, tag, prim, p.leaf_affine, ch);
 }
 
-RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, Arena &A, int tag)      /* Solids.cpp:566-639 */
+template <class AR>
+RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, AR &A, int tag)      /* Solids.cpp:566-639 */
 {
     const double rm = tp.p[0];
     const double lo[3] = { -1.0 - rm, -1.0 - rm, -rm }, hi[3] = { 1.0 + rm, 1.0 + rm, rm };
@@ -777,8 +812,8 @@ struct MeshGlobalSink {
 };
 /* WALK = false (the LITE kernels of a scene whose rays are all pre-walked): a ray without pre-walked crossings (its walk ran
    out of stack) is handed to the FULL kernel, which walks it in line */
-template <bool WALK>
-RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, Arena &A, int tag, const SceneLds &L)
+template <bool WALK, class AR>
+RT_DEVN void mesh_hits(const RtDevScene &S, const RtPrim &mp, uint16_t prim, const DRay &ray, AR &A, int tag, const SceneLds &L)
 {
     const RtMeshInfo mi = S.meshes[mp.plane0];
     const RtMeshTri *tris = S.mesh_tris + mi.tri0;
@@ -831,7 +866,8 @@ RT_DEV uint16_t mat_op(int op, uint16_t l, uint16_t r, const RtMaterialDev *mats
 /* Lists sit in the arena in stack order with increasing start offsets; a merge writes its result above both
    operands and leaves it there (no copy back), so dead records can lie between live lists.  When space runs out
    the live lists are packed down. */
-__device__ void arena_compact(Arena &A)
+template <class AR>
+__device__ void arena_compact(AR &A)
 {
     int top = 0;
     for (int l = 0; l < A.nlist; l++) {
@@ -845,7 +881,8 @@ __device__ void arena_compact(Arena &A)
 }
 
 /* merge the two top lists (left below right) into one that takes the left list's place on the list stack */
-__device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
+template <class AR>
+__device__ void merge_top(AR &A, int op, const RtMaterialDev *mats, int tag)
 {
     int li = A.nlist - 2;
     int lc = A.l_count[li], rc = A.t_count;
@@ -886,15 +923,33 @@ __device__ void merge_top(Arena &A, int op, const RtMaterialDev *mats, int tag)
         list_reload_top(A);
 }
 
-RT_DEV bool top_is(const Arena &A, int tag) { return A.nlist > 0 && A.t_tag == tag; }
-RT_DEV bool second_is(const Arena &A, int tag) { return A.nlist > 1 && A.l_tag[A.nlist - 2] == tag; }
-RT_DEV void drop_top(Arena &A) { A.nlist--; A.top = A.t_start; list_reload_top(A); }
+template <class AR> RT_DEV bool top_is(const AR &A, int tag) { return A.nlist > 0 && A.t_tag == tag; }
+template <class AR> RT_DEV bool second_is(const AR &A, int tag) { return A.nlist > 1 && A.l_tag[A.nlist - 2] == tag; }
+template <class AR> RT_DEV void drop_top(AR &A) { A.nlist--; A.top = A.t_start; list_reload_top(A); }
 
 /* ================================================================== the per-ray stack machine
  * Evaluates psModel->Intersect(ray) (RayTracer2020.h:72): returns the hit list as [start, start+count)
  * in the arena.  tmax bounds the culling tests only (shadow rays stop at t = 1, Shade.cpp:328). */
 /* the innermost union region being folded lives in registers; enclosing ones are saved in private memory */
 struct RegionCur { int ncand, pos, base_lists, nl_before, out_tag, child_pc0, lca0, nchild, uid, end_pc, cur_c, top_idx, top_gap; };
+/* the interpreter's per-ray arrays: the rays of the enclosing affine frames, the saved fold states and candidate lists of the
+   enclosing regions -- private memory, or the lane's part of the pool (ArenaStore<true>) */
+template <bool POOL> struct WalkStore {
+    DRay rs[RT_MAX_AFFINE_DEPTH + 1];
+    RegionCur saved[RT_MAX_REGION_DEPTH];
+    uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
+    template <class AR> RT_DEV void bind(AR &) {}
+};
+static_assert(sizeof(HitRec) == 48 && sizeof(DRay) == 48 && sizeof(RegionCur) == 52, "RT_POOL_STRIDE is written for these sizes");
+template <> struct WalkStore<true> {
+    DRay *rs; RegionCur *saved; uint16_t (*cands)[RT_MAX_CAND];
+    template <class AR> RT_DEV void bind(AR &A)
+    {
+        rs = (DRay *)A.walk;
+        saved = (RegionCur *)(A.walk + (RT_MAX_AFFINE_DEPTH + 1) * sizeof(DRay));
+        cands = (uint16_t (*)[RT_MAX_CAND])(A.walk + (RT_MAX_AFFINE_DEPTH + 1) * sizeof(DRay) + RT_MAX_REGION_DEPTH * sizeof(RegionCur));
+    }
+};
 
 /* min of lca[a .. b-1], a < b (RtRegion sparse table) */
 RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
@@ -1079,14 +1134,15 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
                           RT_SCHED_CLS(OP_UNION, 2) | RT_SCHED_CLS(OP_INTER, 2) | RT_SCHED_CLS(OP_DIFF, 2) | RT_SCHED_CLS(OP_ANGCLIP, 2) | RT_SCHED_CLS(OP_RET, 3) | \
                           RT_SCHED_CLS(OP_REGION, 4) | RT_SCHED_CLS(OP_QUADRIC, 5) | RT_SCHED_CLS(OP_POLY, 5) | RT_SCHED_CLS(OP_SLAB, 5) | RT_SCHED_CLS(OP_CHAIN, 6) | \
                           RT_SCHED_CLS(OP_TORUS, 7) | RT_SCHED_CLS(OP_MESH, 7))
-template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false, bool SCHED = false>
-__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, Arena &A, int &start,
+template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false, bool SCHED = false, class AR>
+__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, AR &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
 {
-    DRay rs[RT_MAX_AFFINE_DEPTH + 1];
+    WalkStore<AR::pool> wst;
+    wst.bind(A);
+    auto &rs = wst.rs; auto &saved = wst.saved; auto &cands = wst.cands;
     A.mesh_slot = mesh_slot;
-    RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 }, saved[RT_MAX_REGION_DEPTH];
-    uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
+    RegionCur cf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1 };
     int nrf = 0;
     int depth = 0;
     DRay cur = wray;            /* the ray in the current frame; rs[] holds the enclosing frames' rays (touched only by non-chain affines) */

@@ -81,6 +81,9 @@ typedef struct RtPipe {
     const unsigned char  *tile_n;
     const unsigned short *tile_cand;
     int64_t               tile_first;
+    /* hit records of the scheduled FULL kernels (ArenaT<true>, rt_core.hip.h): RT_ARENA contiguous 48-byte records per lane of the
+       largest such launch (n_cu x RT_FULL_PER_CU x 256 lanes); null = those kernels are not used */
+    void                 *arena_pool;
 } RtPipe;
 
 typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
