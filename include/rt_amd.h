@@ -142,9 +142,10 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    without being generated),
    "alt_chain" (0/1, default 1: a primary ray whose sampling tile lists a single child of the root region, a bare
    chain, runs that chain alone instead of the region; at rt_scene_upload; results do not depend on it),
-   "tile_need" (0/1/2, default 2: FastBlue reconstruction skips the supersample pixels of tiles farther than twice the
+   "tile_need" (0/1/2/3, default 3: FastBlue reconstruction skips the supersample pixels of tiles farther than twice the
    filter's reach from every tile that can hold a coloured sample -- every output pixel that could read them is 0 whatever
-   they hold -- in the splat gather (1) and in the two resampling passes (2); results do not depend on it),
+   they hold -- in the splat gather (1) and in the two resampling passes (2); 3: the gather does not even write them and the
+   row pass takes them as the zeros they would hold; results do not depend on it),
    "tile_cand" (0/1/2, default 2: the same pass lists, per tile, the children of the root union region a ray through the
    tile can touch -- up to 8; 1: the generator tests those boxes instead of walking the BVH per sample, 2: so does the
    tracing kernel for primary rays; results do not depend on it),
@@ -155,12 +156,22 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    multiple of 1600; results do not depend on it),
    "full_tables" (0/1, default 1: those kernels also read chain records and scene tables from LDS when two of their
    workgroups fit a CU; at rt_scene_upload),
-   "time_kernels" (0/1: HIP events around the k_visual and k_fast launches, read back by rt_probe_work / rt_probe_fast_time),
+   "time_kernels" (0/1: HIP events around the k_visual, k_fast and k_mesh_cross launches, read back by rt_probe_work / rt_probe_fast_time / rt_probe_mesh_time),
    "fast_path" (0/1, default 1: primary rays that can only touch bare chains of the root union region -- two-root primitives
    without texture call-outs, propagators or spectral metals -- are traced by k_fast: no interpreter, no hit arena, hits in
    registers, and no frame where neither a shadow ray nor a child ray is needed; at rt_scene_upload; results do not depend on it),
    "level_sync" (0/1, default 0: 1 makes every pass wait for the host after every level, also where the device-side
-   bounds make that unnecessary; for A/B runs). */
+   bounds make that unnecessary; for A/B runs),
+   "mesh_pre" (0/1/2, default 2: scenes with exactly one mesh instruction walk their rays through the mesh's BVH in a kernel of
+   its own, k_mesh_cross -- 1: the rays the common kernels hand over, before the kernels for the rare features run; 2: every ray
+   of a level, before the common kernels, which then read the crossings themselves; 0: the walk inside the kernels for the rare
+   features; at rt_scene_upload; results do not depend on it),
+   "direct_full" (0/1, default 1: a recursion level of a chunk whose rays the common kernels mostly handed over the last time the
+   same chunk was rendered goes to the kernels for the rare features at once; results do not depend on it),
+   "sched" (0/1/2, default 2 = for programs of 256 instructions and more: those kernels run one class of opcodes per round of
+   the interpreter and keep their per-ray hit records in a pool in global memory, contiguous per lane, instead of private
+   memory -- 1.8 GB on an MI355X (14 KB x 131,072 lanes), part of the queue pool; at rt_scene_upload; results do not depend on it),
+   "direct_launches" (read-only: launches made under direct_full since the library was loaded). */
 int  rt_set_option(const char *name, int64_t value);
 /* the current value of a tunable, -1 (and rt_last_error) for an unknown name */
 int64_t rt_get_option(const char *name);
