@@ -168,7 +168,7 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    features; at rt_scene_upload; results do not depend on it),
    "direct_full" (0/1, default 1: a recursion level of a chunk whose rays the common kernels mostly handed over the last time the
    same chunk was rendered goes to the kernels for the rare features at once; results do not depend on it),
-   "sched" (0/1/2, default 2 = for programs of 256 instructions and more: those kernels run one class of opcodes per round of
+   "sched" (0/1/2, default 2 = for programs of 256 instructions and more: behind the first recursion level those kernels run one class of opcodes per round of
    the interpreter and keep their per-ray hit records in a pool in global memory, contiguous per lane, instead of private
    memory -- 1.8 GB on an MI355X (14 KB x 131,072 lanes), part of the queue pool; at rt_scene_upload; results do not depend on it),
    "direct_launches" (read-only: launches made under direct_full since the library was loaded). */
