@@ -84,6 +84,12 @@ typedef struct RtPipe {
     /* hit records of the scheduled FULL kernels (ArenaT<true>, rt_core.hip.h): RT_ARENA contiguous 48-byte records per lane of the
        largest such launch (n_cu x RT_FULL_PER_CU x 256 lanes); null = those kernels are not used */
     void                 *arena_pool;
+    /* ray order for those kernels (k_sort_keys, rt_kernels.hip): keys in and out (2 x sort_cap), identity values (sort_cap), the
+       origins' box (8 ints) and the radix sort's scratch; null = levels are traced in queue order */
+    unsigned             *sort_keys;
+    int                  *sort_vals, *sort_box;
+    void                 *sort_temp;
+    int                   sort_cap, pad4_;
 } RtPipe;
 
 typedef struct RtSampleGrid {   /* geometry of one render call's sample set */

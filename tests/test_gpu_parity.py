@@ -739,6 +739,27 @@ def test_direct_full_launches_are_invisible(gpu):
     assert seen[1] > seen[0] >= n0 and seen[2] > seen[1]       # from the second render on, the chunk's own memory decides
 
 
+def test_ray_order_is_invisible(gpu):
+    """Option sort_rays: levels that go to the scheduled FULL kernels directly are traced in the order of a key (direction,
+    then cell of the origin) through an index list.  Every ray is traced by the same code and nothing downstream depends on
+    the order, so image and ray counts of S4 are the same with the option off and on -- checked on the renders after the
+    first, which are the ones that take the direct launches."""
+    fs = gpu.FrontScene("S4", "fastblue", optimize=True)
+    out = {}
+    try:
+        for on in (0, 1):
+            gpu.set_options({"sort_rays": on})
+            g = gpu.GpuScene(fs.desc)
+            n0 = gpu.direct_launches()
+            for k in range(3):
+                img, st = g.render(320, 180, 4)
+            assert gpu.direct_launches() > n0          # the third render did run direct launches
+            out[on] = (img, (st.rays_primary, st.rays_shadow, st.rays_secondary, st.hit_overflow))
+    finally:
+        gpu.set_options({"sort_rays": 1})
+    assert out[0][1] == out[1][1] and out[0][1][3] == 0 and np.array_equal(out[0][0], out[1][0])
+
+
 def test_scheduled_interpreter_is_invisible(gpu):
     """Option sched: the FULL kernels of a scene with a long program run one class of opcodes per round (lanes wait for
     each other at the expensive instructions).  Every lane still executes its own instructions in its own order: image and
