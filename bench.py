@@ -177,6 +177,13 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt = float(mx[2])
     rays_all, samples_all = float(tot[0]), float(tot[1])
+    # Row bands overlap: the samples of a band's halo are traced by two ranks.  The job is ONE frame per step, so the rays that
+    # count are the frame's, not the sum over ranks: scale by (samples of the frame) / (samples the ranks traced).
+    halo_factor = 1.0
+    if world > 1 and rank == 0 and samples_all > 0:
+        frame_samples = float(gs.samples(W, H, spp, 0, 0)[2]) * args.steps
+        halo_factor = samples_all / frame_samples
+        rays_all, samples_all = rays_all / halo_factor, frame_samples
 
     if rank == 0:
         res = {
@@ -186,6 +193,7 @@ def main():
             "config": {"workload": "%s %dx%d %g spp FastBlue (BASELINE configs[1] when S0 3840x2160 64, configs[3] when MESH10M)" % (scene_name, W, H, spp),
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "samples_per_step": samples_all / args.steps,
                        "rays_per_step": rays_all / args.steps, "parallelism": "rows%d" % world, "bands": rows,
+                       "halo_factor": halo_factor,     # samples traced by all ranks / samples of the frame (rays and samples above are the frame's)
                        # how rank 0's primary rays were traced: the rest ended in the generator (they miss every box of the scene)
                        "primary_rays_per_step_by_path": {"k_fast": rays_fast / args.steps, "k_visual": rays_interp / args.steps,
                                                           "ended_in_generator": (st.rays_primary - st.rays_fast - st.rays_visual0)},
