@@ -118,7 +118,29 @@ def main():
         ps = rt.FrontScene(args.scene, "test", optimize=True)
         ph, pw = max(16, H // 16), max(16, W // 16)
         preview, _ = rt.GpuScene(ps.desc).render(pw, ph, 1)
-        rows = sh.balanced_bands(sh.row_cost_from_preview(preview, H), world)
+        cost = sh.row_cost_from_preview(preview, H)
+        rows = sh.balanced_bands(cost, world)
+        # ... then corrected by measurement, before any warm-up or timed step: every rank renders its band (the second of two
+        # renders is timed with events on its own GPU), the times are all-gathered (N floats) and every rank cuts the same new
+        # bands (sharding.rebalance).  A renderer of an animation would do the same from the frame before.
+        calib = torch.zeros((3, H, W), dtype=torch.float32, device="cuda")
+        cstream = torch.cuda.current_stream().cuda_stream
+        for _ in range(int(os.environ.get("RT_BENCH_REBALANCE_ROUNDS", "3"))):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ms = 0.0
+            if rows[rank + 1] > rows[rank]:
+                gs.render_device(W, H, spp, calib.data_ptr(), cstream, rows[rank], rows[rank + 1])
+                e0.record()
+                gs.render_device(W, H, spp, calib.data_ptr(), cstream, rows[rank], rows[rank + 1])
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+            mine = torch.tensor([ms], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            got = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            cost, rows = sh.rebalance(cost, rows, [float(t[0]) for t in got])
+        del calib
+        note("bands after measured rebalancing: %s" % rows)
     else:
         rows = sh.row_bands(H, world)
     row0, row1 = rows[rank], rows[rank + 1]

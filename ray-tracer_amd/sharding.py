@@ -41,6 +41,31 @@ def row_cost_from_preview(preview, height, hit_weight=6.6):
     return (1.0 + hit_weight * sm[idx]).tolist()
 
 
+def rebalance(row_cost, bands, times, damping=1.0):
+    """Measured feedback for the cost model: rank r needed times[r] for rows [bands[r], bands[r+1]) whose modelled cost was
+    the sum of row_cost over them; every row of that band is rescaled so that the model reproduces the measurement (rows
+    keep their relative cost within a band), and the bands are cut again.  A rank with an empty band or without a measurement
+    leaves its rows as they are.  Deterministic: every rank computes the same bands from the same gathered times.
+    Returns (new_row_cost, new_bands)."""
+    world = len(bands) - 1
+    cost = list(row_cost)
+    tot_c = sum(cost)
+    tot_t = sum(t for t in times if t > 0.0)
+    if world <= 1 or tot_c <= 0.0 or tot_t <= 0.0:
+        return cost, list(bands)
+    for r in range(world):
+        a, b = bands[r], bands[r + 1]
+        c = sum(cost[a:b])
+        if b <= a or c <= 0.0 or not times[r] > 0.0:
+            continue
+        f = (times[r] / tot_t) / (c / tot_c)            # measured share / modelled share
+        f = 1.0 + damping * (f - 1.0)
+        f = min(4.0, max(0.25, f))
+        for j in range(a, b):
+            cost[j] *= f
+    return cost, balanced_bands(cost, world)
+
+
 def plan_rows(rt_lib, desc_cls, sampler, width, height, spp, row0, row1):
     """rt_plan_rows (include/rt_amd.h): supersample rows and tile rows a band needs.  Host only."""
     out = (C.c_int * 8)()

@@ -164,3 +164,27 @@ def test_balanced_bands_equalise_cost():
     cost = rt.sharding.row_cost_from_preview(prev, 320)
     b = rt.sharding.balanced_bands(cost, 4)
     assert b[1] > 80 and b[3] < 240 and (b[2] - b[1]) < 80
+
+
+def test_rebalance_converges_on_the_true_cost():
+    """sharding.rebalance: bands cut from a wrong cost model (flat) converge to equal measured times within a few rounds when
+    every rank reports the time of its band under the true cost; deterministic, bands stay a partition."""
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    rng = np.random.default_rng(11)
+    h, world = 2160, 8
+    true = 1.0 + 9.0 * np.exp(-((np.arange(h) - 1100.0) / 300.0) ** 2) + 0.2 * rng.random(h)     # a hump in the middle of the picture
+    cost = [1.0] * h
+    bands = rt.sharding.balanced_bands(cost, world)
+    first = None
+    for it in range(4):
+        times = [float(true[bands[r]:bands[r + 1]].sum()) + 0.3 for r in range(world)]         # + a fixed cost per call
+        eff = sum(times) / (world * max(times))
+        first = eff if first is None else first
+        cost, bands = rt.sharding.rebalance(cost, bands, times)
+        assert len(bands) == world + 1 and bands[0] == 0 and bands[-1] == h and all(bands[i] <= bands[i + 1] for i in range(world))
+    times = [float(true[bands[r]:bands[r + 1]].sum()) + 0.3 for r in range(world)]
+    assert first < 0.6 and sum(times) / (world * max(times)) > 0.93
+    # a rank without a measurement (an empty band, a failed timer) leaves the model of its rows alone
+    c2, b2 = rt.sharding.rebalance([1.0] * 100, [0, 50, 50, 100], [1.0, 0.0, 1.0])
+    assert b2[0] == 0 and b2[-1] == 100 and len(c2) == 100

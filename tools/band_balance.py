@@ -34,3 +34,20 @@ for world in (2, 4, 8):
                 torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
             print("%s world %d %-8s full %.1f ms  slowest band %.1f ms  -> efficiency %.2f   bands %s" %
                   (scene, world, name, 1e3 * full, 1e3 * max(ts), full / (world * max(ts)), bands))
+
+# measured feedback (sharding.rebalance, what bench.py does before its warm-up at N > 1): bands from the preview model, then
+# three rounds of "every rank times its band, the model is rescaled band by band, the bands are cut again"
+for world in (2, 4, 8):
+    cost = rt.sharding.row_cost_from_preview(prev, H)
+    bands = rt.sharding.balanced_bands(cost, world)
+    for rnd in range(4):
+        ts = []
+        for r in range(world):
+            if bands[r] == bands[r + 1]:
+                ts.append(0.0); continue
+            gs.render_device(W, H, spp, planes.data_ptr(), 0, bands[r], bands[r + 1])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            gs.render_device(W, H, spp, planes.data_ptr(), 0, bands[r], bands[r + 1])
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print("%s world %d feedback round %d  slowest band %.2f ms  -> efficiency %.2f   bands %s" % (scene, world, rnd, 1e3 * max(ts), full / (world * max(ts)), bands))
+        cost, bands = rt.sharding.rebalance(cost, bands, ts)
