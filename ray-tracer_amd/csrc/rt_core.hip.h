@@ -306,7 +306,7 @@ __device__ void hit_list(W &w, AR &A, int tag, uint16_t prim, int leaf_affine)
     }
     int nout = w.count - first;
     if (nout <= 0) return;
-    if (A.top + nout > RT_ARENA) arena_compact(A);
+    if (A.top + nout > RT_ARENA_SOFT) arena_compact(A);
     if (A.top + nout > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return; }
     /* materials alternate from the far end: the last hit enters nRayInsideAtInfinity's material */
     int inside = w.inside_inf;
@@ -356,7 +356,7 @@ struct ArenaEmit {
     AR &A; int tag;
     RT_DEV bool begin(int L)
     {
-        if (A.top + L > RT_ARENA) arena_compact(A);
+        if (A.top + L > RT_ARENA_SOFT) arena_compact(A);
         if (A.top + L > RT_ARENA || A.nlist >= RT_LIST_STACK) { A.overflow |= (A.nlist >= RT_LIST_STACK) ? OVF_LISTS : OVF_ARENA; return false; }
         return true;
     }
@@ -886,7 +886,7 @@ __device__ void merge_top(AR &A, int op, const RtMaterialDev *mats, int tag)
 {
     int li = A.nlist - 2;
     int lc = A.l_count[li], rc = A.t_count;
-    if (A.top + lc + rc > RT_ARENA) arena_compact(A);
+    if (A.top + lc + rc > RT_ARENA_SOFT) arena_compact(A);
     int ls = A.l_start[li], rs = A.t_start;
     int out = A.top, nout = 0;
     if (out + lc + rc > RT_ARENA) { A.overflow |= OVF_ARENA; A.nlist -= 1; A.top = rs; list_reload_top(A); list_retag_top(A, tag); return; }

@@ -21,7 +21,10 @@
 #define RT_MAX_AFFINE_DEPTH 12      /* nested (merged) affine levels on a root-to-leaf path */
 #define RT_MAX_TEX          4       /* textured Material/Surface ancestors per hit */
 #define RT_LIST_STACK       24      /* pending non-empty hit lists per ray */
-#define RT_ARENA            256     /* working hits per ray (private memory) */
+#define RT_ARENA            512     /* working hits per ray (private memory, or the lane's part of the pool) */
+#define RT_ARENA_SOFT       256     /* ... of which the first 256 are used while the live lists fit there: dead records are packed out when a
+                                       new list would end above this mark (arena_compact), so that a ray's records stay in as little memory as
+                                       possible; only a ray with more live hits than this goes higher (the last Laboratory frames do) */
 #define RT_MAX_LIGHTS       8
 #define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
 #define RT_MAX_CAND         64      /* children of one union region whose boxes a ray may touch */

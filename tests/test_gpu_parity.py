@@ -706,7 +706,7 @@ def test_laboratory_frames_match_oracle(gpu, oracle, name):
     """8(f) conformance case: frames of Laboratory() (LaboratoryAnimation.cpp:387-442; BASELINE configs[4] without the
     Atmosphere stub) -- Pyrex glassware built from differences of unions of quadrics, tori, angular clips and
     hyperboloids under nested bounding boxes, a pseudo-helix of up to eight turns, ColoredGlass, five bumpy spectral
-    metals, a copper stand.  Deep hit lists (the reason RT_ARENA is 256).  Ray counts equal, image to the tolerance of
+    metals, a copper stand.  Deep hit lists (the reason RT_ARENA is 512, used from the bottom).  Ray counts equal, image to the tolerance of
     the libm calls on the path (torus cubic, exp)."""
     opt, raw, g, o = _pair(gpu, oracle, name, "fastblue")
     img, st = g.render(160, 90, 4)
@@ -737,6 +737,19 @@ def test_direct_full_launches_are_invisible(gpu):
         assert np.array_equal(img, ref), k
         assert (st.rays_primary, st.rays_shadow, st.rays_secondary, st.hit_overflow) == (rst.rays_primary, rst.rays_shadow, rst.rays_secondary, 0), k
     assert seen[1] > seen[0] >= n0 and seen[2] > seen[1]       # from the second render on, the chunk's own memory decides
+
+
+def test_last_laboratory_frame_fits_the_hit_arena(gpu):
+    """The last frames of Laboratory() (t near 6: the helix at its full eight turns) have rays with more than 256 hits alive
+    at once; at the reference's own size (1920 x 1080, 4 spp) they used to end the render with RT_ERR_HIT_OVERFLOW.  RT_ARENA
+    is 512 now (the first 256 records are used while the live lists fit there).  The frame renders, and a band of it equals
+    the same rows rendered alone."""
+    fs = gpu.FrontScene("S4@6.0", "fastblue", optimize=True)
+    g = gpu.GpuScene(fs.desc)
+    img, st = g.render(1920, 1080, 4)
+    assert st.hit_overflow == 0 and np.isfinite(img).all() and st.rays() > 10 * st.samples
+    band, bst = g.render(1920, 1080, 4, row0=500, row1=540)
+    assert bst.hit_overflow == 0 and np.array_equal(band[:, 500:540, :], img[:, 500:540, :])
 
 
 def test_ray_order_is_invisible(gpu):
