@@ -256,16 +256,32 @@ def frames_mode(args, rt, torch, dist, world, rank, rehearse):
     stream = torch.cuda.current_stream().cuda_stream
     owner = {i: r for r in range(world) for i in assign[r]}
 
+    uses = {}
+    for step_i in range(args.warmup + args.steps):
+        for j in assign[rank]:
+            gi = (step_i * per_step + j) % len(times)
+            uses[gi] = uses.get(gi, 0) + 1
+
     def step(step_i):
         rays = samples = 0
         mine = {}
+        done = []
         for n, j in enumerate(assign[rank]):
             gi = (step_i * per_step + j) % len(times)
+            tq = time.perf_counter()
             st = scenes[gi][1].render_device(W, H, spp, bufs[n].data_ptr(), stream)
+            if os.environ.get("RT_BENCH_FRAME_TIMES"):
+                torch.cuda.synchronize(); note("frame %d (t = %.4f): %.1f ms" % (gi, times[gi], 1e3 * (time.perf_counter() - tq)))
             rays += st.rays()
             samples += st.samples
             mine[j] = bufs[n]
+            done.append(gi)
         got = sh.gather_frames(mine, owner, rank, world, dist)
+        for gi in done:             # a frame that is not rendered again gives its queues (tens of GB) back
+            uses[gi] -= 1
+            if uses[gi] == 0 and not os.environ.get("RT_BENCH_KEEP_SCENES"):
+                torch.cuda.synchronize()
+                del scenes[gi]
         return rays, samples, len(got)
 
     def barrier():

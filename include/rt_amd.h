@@ -175,6 +175,9 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    direction octant and dominant axis, then the Morton cell of the origin -- sorted on the device; results do not depend on it),
    "direct_pct_deep" (default 40: the share of a level's rays the common kernels must have handed over for a sorted level to go
    to the kernels for the rare features directly; 60 for the other levels),
+   "pool_cache" (0/1, default 1: the queue pool of a scene that is freed is kept -- at most two per process -- and taken over by the
+   next scene on the same device that needs one, instead of being given back and allocated again: an animation uploads a scene per
+   frame; setting it to 0 gives the kept pools back at once),
    "direct_launches" (read-only: launches made under direct_full since the library was loaded). */
 int  rt_set_option(const char *name, int64_t value);
 /* the current value of a tunable, -1 (and rt_last_error) for an unknown name */
