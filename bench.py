@@ -61,6 +61,65 @@ def note(msg):
 T_START = time.perf_counter()
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): this process -- which has not touched the
+    GPU and never will -- starts N fresh children, one rank per GPU (RANK, LOCAL_RANK, WORLD_SIZE, 127.0.0.1 and a free
+    port), relays rank 0's JSON line and exits non-zero if any child does.  The reference's own marker for where this
+    parallelism belongs: "This is where forking multiple threads can happen" (Sampling.cpp:313-314, RayTracer2020.h:182).
+    A child that fails takes the others down with it (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc, out0 = 0, b""
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            if r == 0:
+                try:
+                    out0 += procs[0].communicate(timeout=0.2)[0] or b""
+                except subprocess.TimeoutExpired:
+                    continue
+            elif procs[r].poll() is None:
+                continue
+            live.discard(r)
+            if procs[r].returncode != 0:
+                rc = rc or procs[r].returncode or 1
+                print("[bench] rank %d exited with %d" % (r, procs[r].returncode), file=sys.stderr, flush=True)
+                for q in sorted(live):              # exactly the children started above
+                    procs[q].kill()
+        if live and 0 not in live:
+            time.sleep(0.05)
+    for line in out0.decode(errors="replace").splitlines():     # the JSON line to stdout; anything a library printed beside it to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+    return rc if rc >= 0 else 1
+
+
+def launcher_selftest():
+    """What a child does under RT_BENCH_LAUNCHER_SELFTEST=1 (tests/test_multi_rank.py, no GPU): join the group the launcher
+    described, run one collective, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if os.environ.get("RT_BENCH_LAUNCHER_SELFTEST") == "fail" and rank == world - 1:
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "sum_of_ranks_plus_one": float(t[0]),
+                          "local_rank": int(os.environ["LOCAL_RANK"]), "master": os.environ["MASTER_ADDR"]}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +133,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opts", default=os.environ.get("RT_OPTS", ""), help="library tunables for A/B runs: name=value,...")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("RT_BENCH_LAUNCHER_SELFTEST"):
+        return launcher_selftest()
 
     import torch
     import __graft_entry__ as ge

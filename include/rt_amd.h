@@ -170,7 +170,8 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    same chunk was rendered goes to the kernels for the rare features at once; results do not depend on it),
    "sched" (0/1/2, default 2 = for programs of 256 instructions and more: behind the first recursion level those kernels run one class of opcodes per round of
    the interpreter and keep their per-ray hit records in a pool in global memory, contiguous per lane, instead of private
-   memory -- 1.8 GB on an MI355X (14 KB x 131,072 lanes), part of the queue pool; at rt_scene_upload; results do not depend on it),
+   memory -- 3.45 GB on an MI355X (RT_POOL_STRIDE = 26,304 B x 131,072 lanes: 512 hit records of 48 B, the list stack and the
+   interpreter's arrays per lane), part of the queue pool; the kernels for the rare features also reserve 24 KB of private memory per lane; at rt_scene_upload; results do not depend on it),
    "sort_rays" (0/1, default 1: the levels behind the first that go to the kernels for the rare features directly are traced in the order of a key --
    direction octant and dominant axis, then the Morton cell of the origin -- sorted on the device; results do not depend on it),
    "direct_pct_deep" (default 40: the share of a level's rays the common kernels must have handed over for a sorted level to go

@@ -98,12 +98,13 @@ class PendingGather:
         return self.planes
 
 
-def gather_bands_async(planes, bands, rank, world, dist):
+def gather_bands_async(planes, bands, rank, world, dist, force=False):
     """gather_bands without waiting: the collective is queued behind the work already on the current stream (the band's
     render) and runs beside whatever is queued next -- the following frame's render into ANOTHER buffer.  The caller
-    calls finish() on the returned object before it reads planes on rank 0 or reuses the buffer."""
+    calls finish() on the returned object before it reads planes on rank 0 or reuses the buffer.
+    force: run the collective at world size 1 too (a group of one: how the RCCL path is exercised on a one-GPU box)."""
     import torch
-    if world == 1:
+    if world == 1 and not (force and dist is not None):
         return PendingGather(planes, bands, rank, world, None, None)
     maxrows = max(bands[r + 1] - bands[r] for r in range(world))
     row0, row1 = bands[rank], bands[rank + 1]
@@ -116,11 +117,11 @@ def gather_bands_async(planes, bands, rank, world, dist):
     return PendingGather(planes, bands, rank, world, work, out, slab)
 
 
-def gather_bands(planes, bands, rank, world, dist):
+def gather_bands(planes, bands, rank, world, dist, force=False):
     """planes: torch tensor [3][H][W] whose rows bands[rank]:bands[rank+1] this rank has rendered.  After the call
     rank 0's planes holds every band.  One torch.distributed.gather (RCCL on GPUs, gloo on CPU) of equal-size slabs."""
     import torch
-    if world == 1:
+    if world == 1 and not (force and dist is not None):
         return planes
     maxrows = max(bands[r + 1] - bands[r] for r in range(world))
     row0, row1 = bands[rank], bands[rank + 1]
@@ -155,12 +156,12 @@ def frame_assignment(n_frames, world):
     return [list(range(r, n_frames, world)) for r in range(world)]
 
 
-def gather_frames(frames, owner_of, rank, world, dist):
+def gather_frames(frames, owner_of, rank, world, dist, force=False):
     """Collect whole frames on rank 0.  frames: {frame index: tensor [3][H][W]} rendered by this rank; owner_of: frame
     index -> rank, for every frame of the batch.  One torch.distributed.gather per round of `world` frames (RCCL on
     GPUs, gloo on CPU): in round k every rank that has a k-th frame sends it.  Returns {index: tensor} on rank 0."""
     import torch
-    if world == 1:
+    if world == 1 and not (force and dist is not None):
         return dict(frames)
     per_rank = [[i for i in sorted(owner_of) if owner_of[i] == r] for r in range(world)]
     rounds = max(len(p) for p in per_rank)

@@ -188,3 +188,92 @@ def test_rebalance_converges_on_the_true_cost():
     # a rank without a measurement (an empty band, a failed timer) leaves the model of its rows alone
     c2, b2 = rt.sharding.rebalance([1.0] * 100, [0, 50, 50, 100], [1.0, 0.0, 1.0])
     assert b2[0] == 0 and b2[-1] == 100 and len(c2) == 100
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` with no launcher around it (the driver's own command line) must start N ranks itself:
+    the parent never touches the GPU, gives every child RANK / LOCAL_RANK / WORLD_SIZE / 127.0.0.1 and a free port, and
+    relays rank 0's one JSON line.  The children run the launcher's self-test instead of a render (no GPU here)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RT_BENCH_LAUNCHER_SELFTEST": "1"})
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["launcher_selftest"] is True and res["n_gpus"] == 2 and res["sum_of_ranks_plus_one"] == 3.0
+    assert res["local_rank"] == 0 and res["master"] == "127.0.0.1"
+    r3 = _run_bench(["--gpus", "3"], {"RT_BENCH_LAUNCHER_SELFTEST": "1"})
+    assert r3.returncode == 0 and json.loads(r3.stdout.strip())["n_gpus"] == 3
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """a child that exits non-zero ends the job: the others are stopped (they would wait in the collective) and the
+    launcher's exit code says so"""
+    r = _run_bench(["--gpus", "2"], {"RT_BENCH_LAUNCHER_SELFTEST": "fail"}, timeout=120)
+    assert r.returncode != 0
+    assert "rank 1 exited with 3" in r.stderr
+
+
+_NCCL_WORLD1 = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import __graft_entry__ as ge
+rt = ge.load_package()
+torch.cuda.set_device(0)
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = %r
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+W, H, spp = 96, 64, 4
+fs = rt.FrontScene("S1", "fastblue", optimize=True)
+gs = rt.GpuScene(fs.desc)
+ref, _ = gs.render(W, H, spp)
+stream = torch.cuda.current_stream().cuda_stream
+frames = [torch.zeros((3, H, W), dtype=torch.float32, device="cuda") for _ in range(2)]
+bands = [0, H]
+pend = None
+for k in range(3):          # bench.py's pipeline: the gather of frame k beside the render of frame k + 1
+    planes = frames[k %% 2]
+    gs.render_device(W, H, spp, planes.data_ptr(), stream, 0, 0)
+    g = rt.sharding.gather_bands_async(planes, bands, 0, 1, dist, force=True)
+    assert g.work is not None and g.out is not None and g.out[0].is_cuda
+    if pend is not None:
+        pend.finish()
+    pend = g
+pend.finish()
+torch.cuda.synchronize()
+for f in frames:
+    assert np.array_equal(f.cpu().numpy(), ref)
+out = rt.sharding.gather_bands(frames[0].clone(), bands, 0, 1, dist, force=True)
+assert np.array_equal(out.cpu().numpy(), ref)
+got = rt.sharding.gather_frames({0: frames[0], 1: frames[1] * 2.0}, {0: 0, 1: 0}, 0, 1, dist, force=True)
+assert sorted(got) == [0, 1] and got[0].is_cuda
+assert np.array_equal(got[0].cpu().numpy(), ref) and np.array_equal(got[1].cpu().numpy(), ref * np.float32(2.0))
+t = torch.tensor([1.0, 2.0], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL-WORLD1-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_gather_at_world_size_one():
+    """The RCCL branch of bench.py (backend "nccl", device tensors) on the one GPU there is: a group of one rank goes
+    through the same init, gather_bands_async / finish pipeline, gather_frames and reductions as N ranks would, in a
+    process of its own (so that RCCL's buffers and streams do not stay behind in the test process)."""
+    import subprocess
+    port = str(29300 + os.getpid() % 500)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _NCCL_WORLD1 % (ROOT, port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL-WORLD1-OK" in r.stdout, r.stdout + r.stderr
