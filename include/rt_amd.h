@@ -108,6 +108,15 @@ int  rt_probe_radiance(rt_scene *s, int n, const double *org3, const double *dir
 /* Per-sample RGB of a render (what is splatted), in loop order: float[3*samples]. */
 int  rt_probe_sample_rgb(rt_scene *s, const RtRenderDesc *rd, float *out_rgb, int64_t max_samples, RtStats *stats);
 
+/* Leaf functions the reference spot-checks on their own, same device code as the render path, no scene needed.
+   rt_probe_noise: BandNoise(p, 3) (Texture.cpp:98-123), FractalNoise(p, 3, 5, 1.0f, 1.9f, 0) (:200-241) and Voronoi(p) (:334-374) at n
+   points p3[3n] -- what TestBandNoise (Test.cpp:1635-1653) and TestVoronoi (Test.cpp:3798-3836) print.
+   rt_probe_fresnel: FresnelLaw_Real (Shade.cpp:90-113) for indices (n1, n2) at n cosines -> out_F, out_fNT; and, when out_spec10 is
+   given, Fresnel_Spectral (Shade.cpp:117-153) of the spectral metal `metal_luster` (MAT_COPPER .. MAT_TITANIUM) seen from a medium
+   of index n1 -- the sweep of TestFresnel (Test.cpp:1467-1515); another luster: FresnelLaw_Complex with the real indices. */
+int  rt_probe_noise(int n, const float *p3, float *out_band, float *out_fractal5, float *out_voronoi);
+int  rt_probe_fresnel(int n, const double *cos_ne, double n1, double n2, int metal_luster, double *out_F, double *out_fNT, float *out_spec10);
+
 /* BuildQuasiIndex (Patterns.cpp:1723-1736), RandomUnsigned (MonteCarlo.h:17-27): host-side integer helpers. */
 void rt_build_quasi_index(int *out, int prime, int n);
 void rt_random_unsigned(uint32_t state_xc[2], int n, uint32_t *out);

@@ -102,6 +102,12 @@ class OracleScene:
         self.L.orc_radiance(self.h, n, _p(org, C.c_double), _p(dr, C.c_double), a, _p(out, C.c_float))
         return out
 
+    def node_extent(self, index):
+        """GetExtent of node `index` of the description (Solids.cpp:922-947 and the set operations'): min[3], max[3]."""
+        out = np.zeros(6)
+        self.L.orc_node_extent(self.h, int(index), _p(out, C.c_double))
+        return out
+
     def check_bounding_boxes(self):
         return self.L.orc_check_bounding_boxes(self.h)
 
@@ -115,6 +121,34 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def noise_probe2(p3):
+    """BandNoise(p, 3), FractalNoise(p, 3, 5, 1.0f, 1.9f, 0), Voronoi(p) at points p3[n][3] (TestBandNoise, TestVoronoi)."""
+    L = lib()
+    p3 = np.ascontiguousarray(p3, dtype=np.float32); n = len(p3)
+    band = np.zeros(n, dtype=np.float32); frac = np.zeros(n, dtype=np.float32); vor = np.zeros(n, dtype=np.float32)
+    L.orc_noise_probe2.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_noise_probe2(n, _p(p3, C.c_float), _p(band, C.c_float), _p(frac, C.c_float), _p(vor, C.c_float))
+    return band, frac, vor
+
+
+def fresnel_probe(cos_ne, n1, n2, metal_luster=0):
+    """FresnelLaw_Real (F, fNT) for (n1, n2); Fresnel_Spectral of a metal luster seen from n1 (TestFresnel)."""
+    L = lib()
+    c = np.ascontiguousarray(cos_ne, dtype=np.float64); n = len(c)
+    F = np.zeros(n); T = np.zeros(n); sp = np.zeros((n, 10), dtype=np.float32)
+    L.orc_fresnel_probe.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    L.orc_fresnel_probe(n, _p(c, C.c_double), float(n1), float(n2), int(metal_luster), _p(F, C.c_double), _p(T, C.c_double), _p(sp, C.c_float))
+    return F, T, sp
+
+
+def random_double(n, x=886459, c=361290869):
+    """n RandomDouble draws from the MWC state (x, c) (MonteCarlo.h:35-39; default seeds MonteCarlo.cpp:9-10)."""
+    st = np.array([x, c], dtype=np.uint32)
+    out = np.zeros(n)
+    lib().orc_random_double(_p(st, C.c_uint32), n, _p(out, C.c_double))
+    return out
 
 
 def build_quasi_index(prime, n):

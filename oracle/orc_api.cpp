@@ -345,6 +345,24 @@ extern "C" void orc_noise_probe(int n, const float *p3, float *out_band, float *
     }
 }
 
+/* TestBandNoise (Test.cpp:1635-1653) and TestVoronoi (Test.cpp:3798-3836) evaluate the scalar noises on their own: BandNoise(p, 3),
+   FractalNoise(p, 3, 5, 1.0f, 1.9f, 0) and Voronoi(p) at n points */
+extern "C" void orc_noise_probe2(int n, const float *p3, float *out_band, float *out_fractal5, float *out_voronoi)
+{
+    for (int i = 0; i < n; i++) {
+        float g[3];
+        out_band[i] = band_noise(p3 + 3 * i, 3);
+        out_fractal5[i] = fractal_noise_export(p3 + 3 * i, 3, 5, 0);
+        out_voronoi[i] = gradient_voronoi(g, p3 + 3 * i, 1);
+    }
+}
+
+/* TestFresnel (Test.cpp:1467-1515): the Fresnel routines at n cosines */
+extern "C" void orc_fresnel_probe(int n, const double *cos_ne, double n1, double n2, int metal_luster, double *out_F, double *out_fNT, float *out_spec10)
+{
+    for (int i = 0; i < n; i++) fresnel_probe(cos_ne[i], n1, n2, metal_luster, out_F + i, out_fNT + i, out_spec10 ? out_spec10 + (size_t)NSPEC * i : 0);
+}
+
 extern "C" void orc_roots_probe(const double *coef5, double *roots4, int *count, double *cbrt_in_out, int ncbrt)
 {
     *count = solve_quartic(roots4, coef5[0], coef5[1], coef5[2], coef5[3], coef5[4]);

@@ -148,6 +148,23 @@ static Spec fresnel_spectral(double fNE, double n1, const Spec &nn, const Spec &
     return s;
 }
 
+/* the three Fresnel routines on their own (TestFresnel, Test.cpp:1467-1515): FresnelLaw_Real for (n1, n2); Fresnel_Spectral of a
+   spectral metal seen from a medium of index n1 when metal_luster names one (spec10), else FresnelLaw_Complex with real indices */
+void fresnel_probe(double fNE, double n1, double n2, int metal_luster, double *F, double *fNT, float *spec10)
+{
+    *F = 0.0; *fNT = 0.0;
+    fresnel_real(fNE, n1, n2, *F, *fNT);
+    if (!spec10) return;
+    if (metal_luster >= RT_MAT_COPPER && metal_luster <= RT_MAT_TITANIUM) {
+        Spec s = fresnel_spectral(fNE, n1, g_t.metal_n[metal_luster], g_t.metal_k[metal_luster]);
+        memcpy(spec10, s.v, sizeof(float) * NSPEC);
+    } else {
+        double Fc = 0.0, fNTc = 0.0;
+        fresnel_complex(fNE, Cx(n1, 0.0), Cx(n2, 0.0), Fc, fNTc);
+        for (int i = 0; i < NSPEC; i++) spec10[i] = float(Fc);
+    }
+}
+
 static inline bool spectral_metal(int luster) { return luster >= RT_MAT_COPPER && luster <= RT_MAT_TITANIUM; }
 static inline int roughness(const Hit &h) { return h.surf ? h.surf->i0 : RT_SURF_MATTE; }   /* Q11 */
 

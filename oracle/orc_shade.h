@@ -43,6 +43,9 @@ extern Tables g_t;
 
 float band_noise(const float *p, int ndim);
 float gradient_band_noise(float *g, const float *p, int ndim);
+float gradient_voronoi(float *grad, const float *p, int npow);
+float fractal_noise_export(const float *p, int ndim, int levels, int absolute);    /* FractalNoise, Texture.cpp:200-241 */
+void  fresnel_probe(double fNE, double n1, double n2, int metal_luster, double *F, double *fNT, float *spec10);    /* Shade.cpp:90-153 */
 void  apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx);
 void  transform_normals_export(Hit &h, const Ctx &cx);   /* TransformNormals, Shade.cpp:264-284 */
 

@@ -188,6 +188,7 @@ static float fractal_noise(const float *p, int ndim, int levels, int absolute)
     }
     return noise / gain + 0.5f;
 }
+float fractal_noise_export(const float *p, int ndim, int levels, int absolute) { return fractal_noise(p, ndim, levels, absolute); }
 static double sawtooth_wave(double x)                   /* TextureMaps.cpp:546-555 */
 {
     x = (0.5 / kPi) * x + 0.25;

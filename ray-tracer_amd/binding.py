@@ -268,6 +268,38 @@ def build_quasi_index(prime, n):
     return out
 
 
+def probe_noise(p3):
+    """rt_probe_noise: BandNoise, FractalNoise (5 levels, lacunarity 1.9) and Voronoi of the device at points p3[n][3]."""
+    L = rt_lib()
+    p3 = np.ascontiguousarray(p3, dtype=np.float32); n = len(p3)
+    band = np.zeros(n, dtype=np.float32); frac = np.zeros(n, dtype=np.float32); vor = np.zeros(n, dtype=np.float32)
+    L.rt_probe_noise.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if L.rt_probe_noise(n, _p(p3, C.c_float), _p(band, C.c_float), _p(frac, C.c_float), _p(vor, C.c_float)):
+        raise RtError("rt_probe_noise: %s" % L.rt_last_error().decode())
+    return band, frac, vor
+
+
+def probe_fresnel(cos_ne, n1, n2, metal_luster=0, spectral=True):
+    """rt_probe_fresnel: FresnelLaw_Real (F, fNT) for (n1, n2) and, with spectral, Fresnel_Spectral of a metal luster seen from n1."""
+    L = rt_lib()
+    c = np.ascontiguousarray(cos_ne, dtype=np.float64); n = len(c)
+    F = np.zeros(n); T = np.zeros(n); sp = np.zeros((n, NSPEC), dtype=np.float32)
+    L.rt_probe_fresnel.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    if L.rt_probe_fresnel(n, _p(c, C.c_double), float(n1), float(n2), int(metal_luster), _p(F, C.c_double), _p(T, C.c_double), _p(sp, C.c_float) if spectral else None):
+        raise RtError("rt_probe_fresnel: %s" % L.rt_last_error().decode())
+    return F, T, sp
+
+
+def clip_planes(half, table, from_origin):
+    """ClipPlanes(Extent(half), rgv<table>, n, from_origin) of the front end (Solids.cpp:801-857): 6 doubles, min then max."""
+    L = frontend_lib()
+    out = np.zeros(6)
+    L.rtf_clip_planes.argtypes = [C.c_double, C.c_char_p, C.c_double, C.POINTER(C.c_double)]
+    if L.rtf_clip_planes(float(half), table.encode(), float(from_origin), _p(out, C.c_double)):
+        raise RtError(L.rtf_last_error().decode())
+    return out
+
+
 def bmp_encode(planes, gamma=-1.0):
     """Image::WriteBMP on the GPU (rt_bmp_encode): the bytes of the 24-bit BMP file of a [3][H][W] float image."""
     L = rt_lib()

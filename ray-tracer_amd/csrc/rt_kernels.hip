@@ -1751,6 +1751,32 @@ __global__ void __launch_bounds__(256) k_probe_work(const RtDevScene Sv, int n, 
     atomicAdd(&out[6], 1ull);
 }
 
+/* ------------------------------------------------------------------ probes: leaf functions the reference tests on their own
+ * TestBandNoise (Test.cpp:1635-1653) / TestVoronoi (Test.cpp:3798-3836): BandNoise(p, 3), FractalNoise(p, 3, 5, 1.0f, 1.9f, 0), Voronoi(p) */
+__global__ void __launch_bounds__(256) k_probe_noise(int n, const float *p3, float omega19, float *out_band, float *out_fractal5, float *out_voronoi)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float p[3] = { p3[3 * k], p3[3 * k + 1], p3[3 * k + 2] };
+    float g[3];
+    out_band[k] = band_noise3(p);
+    out_fractal5[k] = fractal_noise3(p, 5, 0, omega19);
+    out_voronoi[k] = gradient_voronoi(g, p, 1);
+}
+/* TestFresnel (Test.cpp:1467-1515): FresnelLaw_Real for (n1, n2) and Fresnel_Spectral of a metal's n / k spectra (nk: 10 + 10 floats) seen from n1 */
+__global__ void __launch_bounds__(256) k_probe_fresnel(int n, const double *cos_ne, double n1, double n2, const float *nk, double *out_F, double *out_fNT, float *out_spec10)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double F = 0.0, fNT = 0.0;
+    fresnel_real(cos_ne[k], n1, n2, F, fNT);
+    out_F[k] = F; out_fNT[k] = fNT;
+    if (out_spec10) {
+        const Spec s = fresnel_spectral(cos_ne[k], n1, nk, nk + RT_NSPEC);
+        for (int i = 0; i < RT_NSPEC; i++) out_spec10[(size_t)k * RT_NSPEC + i] = s.v[i];
+    }
+}
+
 /* ------------------------------------------------------------------ reconstruction
  * FastBlueSamplingTile splats every sample bilinearly into a supersampled image (Image::FastSplatRGB,
  * Image.cpp:1309-1334), then resamples with a separable Kaiser-windowed sinc (ImageResample,

@@ -406,6 +406,33 @@ static Solid *cage(const CoVector3 *v, int nv, double maxlen, double r, double r
     }
     return new BoundingBox(ps);
 }
+/* Solids.cpp:801-857.  Corner k of the extent takes x, y, z from pMin / pMax by bits 0, 1, 2 of k.  For the plane, the corners
+   with cv * p - fFromOrigin < 0 are kept (in their order) and every kept corner is joined to every dropped one; where such a
+   segment meets the plane is one more point (kept corner outer, dropped corner inner).  The box of all those points is the
+   answer -- the initial extent again when fewer than two points are left.  Only rgcv[0] is looked at: the loop of the reference
+   ends in an unconditional break (:845). */
+Extent ClipPlanes(const Extent &eInitial, const CoVector3 rgcv[], int nv, double fFromOrigin)
+{
+    std::vector<Point3> in, out;
+    const Point3 *c2[2] = { &eInitial.pMin, &eInitial.pMax };
+    for (int k = 0; k < 8; k++) in.push_back(Point3(c2[k & 1]->x, c2[(k >> 1) & 1]->y, c2[(k >> 2) & 1]->z));
+    if (nv > 0) {
+        const CoVector3 &cv = rgcv[0];
+        std::vector<Point3> kept;
+        for (size_t k = 0; k < in.size(); k++) ((cv * in[k] - fFromOrigin < 0.0) ? kept : out).push_back(in[k]);
+        in = kept;
+        for (size_t i = 0; i < kept.size(); i++)
+            for (size_t j = 0; j < out.size(); j++) {
+                const double t = (fFromOrigin - cv * kept[i]) / (cv * (out[j] - kept[i]));
+                in.push_back(kept[i] + (out[j] - kept[i]) * t);
+            }
+    }
+    if (in.size() < 2) return eInitial;
+    Extent e(in[0], in[0]);
+    for (size_t i = 1; i < in.size(); i++) { e.pMin = Min(e.pMin, in[i]); e.pMax = Max(e.pMax, in[i]); }
+    return e;
+}
+
 Solid *TetrahedronCage(double r, double rs) { return cage(rgvTetrahedron, 4, 0.0, r, rs, false); }
 Solid *IcosahedronCage(double r, double rs) { return cage(rgvIcosahedron, 12, 1.1, r, rs, true); }     /* Solids.cpp:1766 uses Tetra(i) when r == 0 */
 Solid *DodecahedronCage(double r, double rs) { return cage(rgvDodecahedron, 20, 0.8, r, rs, false); }

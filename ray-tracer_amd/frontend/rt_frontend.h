@@ -258,6 +258,9 @@ struct ConeHyperCylinder : Quadric {
 };
 
 extern CoVector3 rgvTetrahedron[4], rgvCube[8], rgvOctahedron[6], rgvDodecahedron[20], rgvIcosahedron[12];
+/* ClipPlanes (Solids.h:128, Solids.cpp:801-857): the box around what half space(s) cv * p < fFromOrigin leave of an extent's corner set.
+   As checked in, the reference stops after the first plane; so does this (TestClipPlanes, Test.cpp:1822-1830). */
+Extent ClipPlanes(const Extent &eInitial, const CoVector3 rgcv[], int nv, double fFromOrigin);
 struct ConvexPolyhedron : Solid {
     CoVector3 *rgv; int nSides;
     ConvexPolyhedron() : rgv(0), nSides(0) {}

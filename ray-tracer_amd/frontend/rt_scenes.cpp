@@ -677,6 +677,21 @@ extern "C" int rtf_extent(const char *solid_text, double *out6)
     return 0;
 }
 
+/* ClipPlanes(Extent(half), table, n, from_origin) for one of the polyhedron normal tables ("tetrahedron", "cube", "octahedron",
+   "dodecahedron", "icosahedron"): TestClipPlanes, Test.cpp:1822-1830 */
+extern "C" int rtf_clip_planes(double half, const char *table, double from_origin, double *out6)
+{
+    const CoVector3 *t = 0;
+    int n = 0;
+    const std::string w(table ? table : "");
+    if (w == "tetrahedron") { t = rgvTetrahedron; n = 4; } else if (w == "cube") { t = rgvCube; n = 8; } else if (w == "octahedron") { t = rgvOctahedron; n = 6; }
+    else if (w == "dodecahedron") { t = rgvDodecahedron; n = 20; } else if (w == "icosahedron") { t = rgvIcosahedron; n = 12; }
+    else { snprintf(s_scene_err, sizeof s_scene_err, "unknown normal table %s", w.c_str()); return -1; }
+    const Extent e = ClipPlanes(Extent(half), t, n, from_origin);
+    out6[0] = e.pMin.x; out6[1] = e.pMin.y; out6[2] = e.pMin.z; out6[3] = e.pMax.x; out6[4] = e.pMax.y; out6[5] = e.pMax.z;
+    return 0;
+}
+
 extern "C" void rtf_random_double(unsigned x, unsigned c, int n, double *out)
 {
     ML_InitializeRandom(x, c);

@@ -40,6 +40,18 @@ def _rel_rmse(a, b):
     return float(np.sqrt(((a - b) ** 2).mean()) / max(1e-30, np.sqrt((b ** 2).mean())))
 
 
+def _assert_outliers_are_ties(o, org, dr, aux, bad, rel=1e-9, tries=32):
+    """The rays on which device and oracle disagree beyond rounding must be GRAZING TIES: rays at which the oracle's own radiance is
+    discontinuous, so that a last-bit difference in a libm result (torus cubic, exp) decides differently.  Shown per outlier: among
+    directions jittered by 1e-9 relative the oracle itself returns radiances that differ by more than the tolerance."""
+    rng = np.random.default_rng(99)
+    for k in np.flatnonzero(bad):
+        d = dr[k] * (1.0 + rel * rng.uniform(-1.0, 1.0, (tries, 3)))
+        r = o.radiance(np.tile(org[k], (tries, 1)), d, None if aux is None else np.tile(aux[k], (tries, 1)))
+        r0 = o.radiance(org[k:k + 1], dr[k:k + 1], None if aux is None else aux[k:k + 1])[0]
+        assert not np.isclose(r, r0, rtol=1e-4, atol=1e-6).all(), "ray %d differs between device and oracle but is no tie" % k
+
+
 def test_device_f64_arithmetic_is_ieee(gpu, oracle):
     """Camera rays use +,-,*,/ and sqrt only: any deviation from IEEE rounding on the device shows here."""
     opt, raw, g, o = _pair(gpu, oracle, "S2", "")
@@ -135,7 +147,8 @@ def test_radiance_matches_oracle(gpu, oracle, scene, tol):
         assert np.array_equal(a, b)
     else:
         bad = ~np.isclose(a, b, rtol=1e-4, atol=1e-6).all(axis=1)
-        assert bad.mean() < 2e-3, bad.mean()          # grazing ties only
+        assert bad.mean() < 2e-3, bad.mean()          # grazing ties only ...
+        _assert_outliers_are_ties(o, org, dr, aux, bad)      # ... and each of them is one
         assert _rel_rmse(a[~bad], b[~bad]) <= tol
 
 
@@ -169,6 +182,7 @@ def test_solid_colour_textures(gpu, oracle):
     assert np.isfinite(a).all()
     bad = ~np.isclose(a, b, rtol=1e-4, atol=1e-6).all(axis=1)
     assert bad.mean() < 2e-3, bad.mean()
+    _assert_outliers_are_ties(o, org, dr, aux, bad)
     assert _rel_rmse(a[~bad], b[~bad]) <= 1e-6
     plain = SCENE_COLOUR
     for name in ("voronoi", "agate", "marble", "clouds", "wood", "spots", "veins"):

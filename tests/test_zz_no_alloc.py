@@ -7,6 +7,8 @@ device's free memory does not move across a call; a render beyond the array's si
 import numpy as np
 import pytest
 
+from conftest import SCENE_GLASS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -29,7 +31,11 @@ def _both(g, torch, w, h, spp, r0=0, r1=0):
     return a[:, lo:hi], b[:, lo:hi], sa, sb
 
 
-@pytest.mark.parametrize("scene,sampler", [("S1", "fastblue"), ("S0", "fastblue"), ("S1", "test"), ("S1", "jitter"), ("S0", "adaptive"), ("S1", "bluenoise")])
+# S4 (the Laboratory: deep CSG, glass with propagators, bumpy spectral metals) and the glass scene run kernel sets on this path that
+# rt_render_device does not use for them (no hit-record pool, no ray sorting, no direct FULL launches): same frames all the same
+@pytest.mark.parametrize("scene,sampler", [("S1", "fastblue"), ("S0", "fastblue"), ("S1", "test"), ("S1", "jitter"), ("S0", "adaptive"), ("S1", "bluenoise"),
+                                           ("S4", "fastblue"), (SCENE_GLASS, "fastblue")],
+                         ids=["S1-fastblue", "S0-fastblue", "S1-test", "S1-jitter", "S0-adaptive", "S1-bluenoise", "S4-fastblue", "glass-fastblue"])
 def test_static_render_equals_render_device_twice_in_a_row(gpu, scene, sampler):
     import torch
     fs = gpu.FrontScene(scene, sampler, optimize=True)
