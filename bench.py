@@ -39,6 +39,19 @@ HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join(ROOT, "ray-tracer_amd", "data", "pmc_traffic.json")
 
 
+def library_fingerprint():
+    """sha256 (first 16 hex digits) over the sources librt_amd.so is built from.  tools/pmc_traffic.py stores it with a PMC
+    measurement; `traffic` is reported only while it still names the kernels that are running (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ray-tracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 # BASELINE configs[3]: a synthetic mesh of about ten million triangles (a lobed, star-shaped closed surface of
 # 2 * 3200 * 1562 = 9,996,800 triangles) on a floor, one area light and one point light: every ray walks the mesh's BVH
 MESH_SCENE = """(scene
@@ -380,7 +393,7 @@ def frames_mode(args, rt, torch, dist, world, rank, rehearse):
                        "rays_per_step": float(tot[0]) / args.steps, "samples_per_step": float(tot[1]) / args.steps,
                        **({"rehearsal": "all ranks on one GPU, gloo"} if rehearse else {})},
             "sec_per_frame": dt / (args.steps * per_step) * world,
-            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "roofline": {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                          "note": "frame-parallel mode times whole frames; the kernel roofline is reported by the one-frame mode (--scene S4)"},
         }
         print(json.dumps(res))
@@ -391,7 +404,9 @@ def frames_mode(args, rt, torch, dist, world, rank, rehearse):
 # SURVEY 8d's unit for the mesh workload: visited BVH nodes x node bytes + tested triangles x triangle bytes per ray, counted by
 # the device on the BVH it walks (instrumented build, tools/mesh_count.py, 960x540 4 spp of the same scene: every ray of the
 # scene is walked through the mesh): 15.6 nodes of 64 B and 7.8 triangles of 80 B, plus the 48-byte ray the walk reads
-MESH_WALK_BYTES = {"MESH10M": 15.6 * 64.0 + 7.8 * 80.0 + 48.0}
+MESH_WALK_COUNTS = {"MESH10M": (15.6, 7.8)}        # BVH nodes visited, triangles tested per ray
+MESH_WALK_BYTES = {k: n * 64.0 + t * 80.0 + 48.0 for k, (n, t) in MESH_WALK_COUNTS.items()}
+MESH_WALK_BYTES_SURVEY = {k: n * 32.0 + t * 48.0 for k, (n, t) in MESH_WALK_COUNTS.items()}     # SURVEY 8d's literal weights: 32-byte nodes, 48-byte triangles
 
 
 def mesh_roofline(rt, gs, name, other):
@@ -404,29 +419,34 @@ def mesh_roofline(rt, gs, name, other):
     ms, launches, rays = t
     if launches <= 0 or rays <= 0:
         return dict(other, note="no k_mesh_cross launch was timed (option mesh_pre < 2?): figures of the tracing kernel")
-    b = MESH_WALK_BYTES[name]
+    b, b8d = MESH_WALK_BYTES[name], MESH_WALK_BYTES_SURVEY[name]
     gbs = b * rays / (ms * 1e-3) / 1e9
+    gbs8d = b8d * rays / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_mesh_cross", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None, "traffic_source": None, "bytes_per_ray": b, "rays_per_launch": rays / launches, "ms_per_launch": ms / launches,
             "in_kernel_rays_per_s": rays / (ms * 1e-3), "launches_timed": launches,
-            "note": "bytes_per_ray = 15.6 BVH nodes x 64 B + 7.8 triangles x 80 B + 48 B ray (device counts, tools/mesh_count.py); "
-                    "the walk is bound by memory-level parallelism (dependent node reads), not by bandwidth: DESIGN.md section 6",
-            "tracing_kernel": {k: other.get(k) for k in ("kernel", "achieved", "frac", "bytes_per_ray", "rays_per_launch", "ms_per_launch")}}
+            "survey_8d_weights": {"bytes_per_ray": b8d, "achieved": gbs8d, "frac": gbs8d / HBM_PEAK_GBS,
+                                  "note": "the same event counts priced at SURVEY 8d's literal 32 B per node and 48 B per triangle"},
+            "note": "bytes_per_ray = %.1f BVH nodes x 64 B + %.1f triangles x 80 B (the structures this library walks) + 48 B ray; the counts are the "
+                    "device's own, from the counting build (tools/mesh_count.py, -DRT_MESH_COUNT) on this scene at 960x540, 4 spp -- not re-measured by this run; "
+                    "the walk is bound by memory-level parallelism (dependent node reads), not by bandwidth: DESIGN.md section 6" % MESH_WALK_COUNTS[name],
+            "tracing_kernel": {k: other.get(k) for k in ("kernel", "bound", "achieved", "unit", "frac", "rays_per_launch", "ms_per_launch")}}
 
 
 def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
     """The dominant kernel of the timed steps and its roofs.
 
-    S0-like workloads (most primary rays can only touch bare chains of the root region): k_fast.  It reads an 8-byte queue
-    entry per ray and writes 12 bytes of RGB -- ALGORITHMIC bytes = 20 per ray -- so against the HBM roof it is nowhere
-    (frac of a percent) and says so: the kernel is FP64 VALU work, which is what SURVEY 8d calls this path.  "valu_fp64"
-    holds that view: SURVEY 8d's per-event flop weights x IDEAL-culling event counts (counted by the device on a sample of
-    the workload's camera rays that reach the tracing kernels) x rays per launch / launch duration.  Other workloads:
-    k_visual, whose nearest hard roof is the frame record it streams per ray (56 B read + 4 B flags + 144 B per shaded
-    boundary + 56 B per queued shadow ray, + 16 B per auxiliary pair).  Durations are HIP events on the render stream
-    recorded inside the timed region and read after it.  traffic = HBM bytes per launch from PMC counters (separate
-    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) of the profiles/ run named in traffic_source -- not of this run --
-    and only when this run's launches have the same size."""
+    Analytic-CSG workloads are FP64 VALU work, so the roof is the FP64 vector peak: "bound": "valu_fp64",
+    achieved = SURVEY 8d's per-event flop weights x IDEAL-culling event counts (counted by the device on a sample of the
+    workload's camera rays that reach the tracing kernels) x rays per launch / launch duration.  For S0 SURVEY 8d itself
+    prices "~ 8 box tests" per ray -- that is the headline count; the formula count (2 log2 K + 2 per leaf reached: 21 on
+    S0) is printed beside it.  S0-like workloads (most primary rays can only touch bare chains of the root region): the
+    kernel is k_fast, which reads an 8-byte queue entry per ray and writes 12 bytes of RGB; other workloads: k_visual, which
+    streams a frame record per ray (56 B read + 4 B flags + 144 B per shaded boundary + 56 B per queued shadow ray, + 16 B per
+    auxiliary pair).  Those algorithmic bytes against the HBM roof are the "hbm" view.  Durations are HIP events on the render
+    stream recorded inside the timed region and read after it.  traffic = HBM bytes per launch from PMC counters (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) of the profiles/ run named in traffic_source -- runs of their own, and
+    reported only when they were made with this very build of the library (library_fingerprint) on launches of this size."""
     _, _, total = gs.samples(W, H, spp, 0, 0)
     ntile = total // 1600
     picks = sorted(set(int(x) for x in np.linspace(0, ntile - 1, 64)))
@@ -440,7 +460,7 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
     L.rt_probe_fast_time.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.rt_probe_fast_time(gs.h, fast.ctypes.data_as(C.POINTER(C.c_double)))
     rc = L.rt_probe_work(gs.h, m, org.ctypes.data_as(C.POINTER(C.c_double)), dr.ctypes.data_as(C.POINTER(C.c_double)), work.ctypes.data_as(C.POINTER(C.c_double)))
-    empty = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    empty = {"bound": "valu_fp64", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
     if rc:
         return dict(empty, note="rt_probe_work failed: %s" % L.rt_last_error().decode())
     leaf, affine, boxes_ideal, merged, boundaries, lights, ms_per_launch, rays_per_launch, m_reach = work
@@ -448,9 +468,14 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
         return dict(empty, note="no sampled ray reached a tracing kernel")
     frac_reach = m_reach / m
     m = m_reach         # per-ray figures are over the rays the tracing kernels process
-    per_ray = (leaf * (W_AFFINE + W_QUADRIC) + boxes_ideal * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
-    events = {"leaf_tests": leaf / m, "ideal_box_tests_formula_2log2K_plus_2_per_leaf": boxes_ideal / m, "merged_hits": merged / m,
-              "shaded_boundaries": boundaries / m, "light_terms": lights / m}
+    def flops(boxes):
+        return (leaf * (W_AFFINE + W_QUADRIC) + boxes * W_BOX + merged * W_MERGE + boundaries * W_SHADE + lights * W_SHADE_LIGHT) / m
+    # SURVEY 8d prices S0 with "~ 8 box tests" per ray; the formula 2 log2 K + 2 per leaf reached gives 21 there.  The headline
+    # fraction uses the survey's own count where it names one (S0) and the formula elsewhere; both are printed.
+    per_ray_formula = flops(boxes_ideal)
+    per_ray_survey = flops(8.0 * m) if workload.startswith("S0 ") else per_ray_formula
+    events = {"leaf_tests": leaf / m, "ideal_box_tests_formula_2log2K_plus_2_per_leaf": boxes_ideal / m, "box_tests_survey_8d": 8.0 if workload.startswith("S0 ") else None,
+              "merged_hits": merged / m, "shaded_boundaries": boundaries / m, "light_terms": lights / m}
     d = fs.desc.contents
     area = any(d.lights[i].type == rt.RT_LIGHT_AREA for i in range(d.n_lights))
     fast_ms, fast_launches = fast
@@ -464,22 +489,36 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
             return dict(empty, note="no tracing kernel launch was timed")
         kernel = "k_visual"
         bytes_per_ray = 56.0 + (16.0 if area else 0.0) + 4.0 + 144.0 * boundaries / m + 56.0 * st.rays_shadow / visual_rays
-    gbs = bytes_per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e9
-    ach = per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e12
+    sec = ms_per_launch * 1e-3
+    gbs = bytes_per_ray * rays_per_launch / sec / 1e9
+    ach = per_ray_survey * rays_per_launch / sec / 1e12
+    ach_formula = per_ray_formula * rays_per_launch / sec / 1e12
     traffic = source = None
+    traffic_note = "no PMC measurement of this workload and kernel is on file"
     try:
         with open(TRAFFIC_FILE) as f:
             tf = json.load(f)
         if workload.startswith(tf["workload"]) and tf["kernel"] == kernel and abs(tf["rays_per_launch"] - rays_per_launch) <= 0.02 * rays_per_launch:
-            traffic, source = tf["hbm_bytes_per_launch"], tf["source"] + " (PMC passes of their own, not this run)"
+            if tf.get("library_fingerprint") == library_fingerprint():
+                traffic, source = tf["hbm_bytes_per_launch"], tf["source"] + " (PMC passes of their own over the same workload with this very library: fingerprint %s)" % tf["library_fingerprint"]
+                traffic_note = None
+            else:
+                traffic_note = "the PMC measurement on file (%s) is of another build of the library: not reported" % tf.get("source")
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": source, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
-            "ms_per_launch": ms_per_launch, "in_kernel_rays_per_s": rays_per_launch / (ms_per_launch * 1e-3),
-            "rays_reaching_tracing_kernels": frac_reach,
-            "valu_fp64": {"achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "flops_per_ray": per_ray},
-            "events_per_ray": events}
+    # analytic-CSG workloads are FP64 VALU work, not HBM work: the roof is the FP64 vector peak
+    out = {"bound": "valu_fp64", "kernel": kernel, "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
+           "traffic": traffic, "traffic_source": source, "flops_per_ray": per_ray_survey,
+           "flops_per_ray_basis": "SURVEY 8d weights x ideal-culling event counts" + (", 8 box tests per ray as SURVEY 8d prices S0" if workload.startswith("S0 ") else ", box tests by the formula 2 log2 K + 2 per leaf reached"),
+           "with_formula_box_tests": {"flops_per_ray": per_ray_formula, "achieved": ach_formula, "frac": ach_formula / FP64_VECTOR_PEAK_TFLOPS},
+           "rays_per_launch": rays_per_launch, "ms_per_launch": ms_per_launch, "in_kernel_rays_per_s": rays_per_launch / sec,
+           "rays_reaching_tracing_kernels": frac_reach,
+           "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray,
+                   "note": "algorithmic bytes of the same kernel against the HBM roof: not what bounds it"},
+           "events_per_ray": events}
+    if traffic_note:
+        out["traffic_note"] = traffic_note
+    return out
 
 
 def cpu_baseline(ge, rt, scene, name):

@@ -6,7 +6,8 @@ FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B for every
 (MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is exact for streaming stores.  Both were checked on
 kernels of this library whose byte counts are known (k_resample_rows reads the 8.49 GB supersampled image,
 k_splat_gather writes it)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def sums(d):
@@ -38,7 +39,8 @@ if key:
     n = max(nf[k], nw.get(k, 0), 1)
     rd, wr = 2.0 * 1024.0 * fetch[k], 1024.0 * write.get(k, 0.0)
     r = b["roofline"]
-    json.dump({"workload": b["config"]["workload"].split(" (")[0], "kernel": kernel, "launches_per_frame": n,
+    from bench import library_fingerprint
+    json.dump({"library_fingerprint": library_fingerprint(),"workload": b["config"]["workload"].split(" (")[0], "kernel": kernel, "launches_per_frame": n,
                "rays_per_launch": r["rays_per_launch"], "hbm_bytes_read_per_launch": rd / n, "hbm_bytes_written_per_launch": wr / n,
                "hbm_bytes_per_launch": (rd + wr) / n, "hbm_bytes_per_ray": (rd + wr) / n / r["rays_per_launch"],
-               "algorithmic_bytes_per_ray": r["bytes_per_ray"], "source": source}, open(out, "w"), indent=1)
+               "algorithmic_bytes_per_ray": r["hbm"]["bytes_per_ray"], "source": source}, open(out, "w"), indent=1)
