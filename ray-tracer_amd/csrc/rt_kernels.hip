@@ -1233,6 +1233,295 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
   }
 }
 
+/* ------------------------------------------------------------------ the fast path in two kernels (option fast_split)
+ * k_fast above keeps a ray's whole life in one kernel: f64 geometry (camera ray, chain, hits, walk) and f32 shading (light loop,
+ * BRDF, sRGB) together need the whole register budget of two waves per SIMD and still spill, and its waves spend two thirds of
+ * their cycles waiting.  Split at the boundary the walk stops at, each half fits half the registers and runs at twice the
+ * occupancy:
+ *   k_fast_hit    sample -> camera ray -> chain(s) -> <= 3 hits in registers -> which hit the walk of Shade.cpp:433-511 stops
+ *                 at (the same decisions in the same order as visual_walk, none of its arithmetic) -> a 44-byte record: sample,
+ *                 distance, the hit's normal after the late transform (Shade.cpp:264-284), the materials on either side, the
+ *                 surface.  Rays without a boundary end here (black, or a NOSHADE medium's colour); rays the interpreter must
+ *                 see become root frames, as in k_fast.
+ *   k_fast_shade  record -> the ray again from the sample index (same arithmetic) -> visual_walk over the two-entry list
+ *                 "inside material a at t = 0; boundary hit" (which is where the full walk stood) -> light loop -> RGB, or the
+ *                 frame record and shadow rays k_fast would have left for k_shade.
+ * The record goes through a compact queue (one atomic per wave), never through the frame pool.  Same results as k_fast and as
+ * the interpreter (test_fast_path_is_invisible). */
+#ifndef RT_FASTA_THREADS
+#define RT_FASTA_THREADS 768
+#endif
+#ifndef RT_FAST_CLAIM
+#define RT_FAST_CLAIM 512       /* queue entries a wave of the two kernels claims per atomic */
+#endif
+#ifndef RT_FASTB_THREADS
+#define RT_FASTB_THREADS 512
+#endif
+RT_HD size_t fast_hit_lds_bytes(int n_chains, int n_mats)
+{
+    return (size_t)n_chains * sizeof(RtChain) + (size_t)2 * RT_BLUE_N * sizeof(double) + (size_t)n_mats * sizeof(RtMaterialDev) + 64;
+}
+RT_HD size_t fast_shade_lds_bytes(int n_mats, int n_surfs, int n_lights)
+{
+    return (size_t)2 * RT_BLUE_N * sizeof(double) + (size_t)RT_BLUE_N * sizeof(int32_t) + (size_t)n_mats * sizeof(RtMaterialDev) + (size_t)n_surfs * sizeof(RtSurfaceDev) +
+           (size_t)n_lights * sizeof(RtLightDev) + 64;
+}
+/* FastBlueSamplingTile::Render, Sampling.cpp:498-517 + CastFunction, RayTracer2020.cpp:20-31 for sample sidx of the grid: as sample_at / root_ray
+   (no aperture camera on the fast path: the lens pair is not needed) */
+RT_DEV DRay fast_ray(const RtDevScene &S, const RtSampleGrid &g, const int64_t sidx, uint32_t &tile, int &i)
+{
+    tile = (uint32_t)(sidx / RT_BLUE_N);
+    i = (int)(sidx - (int64_t)tile * RT_BLUE_N);
+    const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+    const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
+    const double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
+    const double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + vtx, vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + vty;
+    const double v0 = (vx + g.adjust_x) / g.size, v1 = (vy + g.adjust_y) / g.size;
+    return camera_emit(S.cam, v0, v1, 0.0, 0.0);
+}
+RT_DEV void fast_aux(const RtDevScene &S, const int i, double *aux)
+{
+    for (int q = 0; q < 6; q++) aux[q] = 0.0;
+    if (S.aux_light) {
+        const int q2 = S.qi2[i % RT_BLUE_N];
+        aux[2] = 2.0 * S.blue[2 * q2] - 1.0;
+        aux[3] = 2.0 * S.blue[2 * q2 + 1] - 1.0;
+    }
+    aux[4] = aux[2]; aux[5] = aux[3];       /* the micro-facet pair follows the light's permutation (Sampling.cpp:512-515) */
+}
+template <int MODE>
+__global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTA_THREADS, 1) k_fast_hit(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, float *out_rgb, float *out_spec)
+{
+    RtDevScene SL = Sv;
+    const RtChain *chains = Sv.chains;
+    if constexpr (MODE == 1) {
+        extern __shared__ double rt_dyn_lds[];
+        double *cur = rt_dyn_lds;
+        chains = lds_stage(cur, Sv.chains, Sv.n_chains);
+        SL.blue = lds_stage(cur, Sv.blue, 2 * RT_BLUE_N);
+        SL.mats = lds_stage(cur, Sv.mats, Sv.n_mats);
+        __syncthreads();
+    }
+    const RtDevScene &S = SL;
+    int n = P.counters[CTR_FAST];
+    if (n > P.ncap) n = P.ncap;
+    int *const work = &P.counters[CTR_WORK_F];
+    const int wlane = threadIdx.x & 63;
+    /* waves claim RT_FAST_CLAIM entries per atomic.  The claims are not free -- k_fast's 280 k same-address atomics per launch (claims
+       of 128) cost it 0.55 of its 3.3 ms -- but dealing the chunks out statically (wave w takes chunks w, w + W, ...) was slower than
+       claims of 512: 2.65 against 2.44 ms per launch; the entries' costs differ enough for the balance to matter */
+  int wnext = 0, wlimit = 0;
+  for (;;) {
+    if (wnext >= wlimit) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, RT_FAST_CLAIM);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        wnext = b; wlimit = b + RT_FAST_CLAIM < n ? b + RT_FAST_CLAIM : n;
+    }
+    const int e = wnext + wlane;
+    wnext += 64;
+    const bool live = e < n;
+    int k = 0;
+    bool hand_over = false, boundary = false;
+    double bt = 0.0;
+    D3 bn = d3(0, 0, 0);
+    int bids = 0, bsurf = 0;
+    if (live) {
+        k = nt_load(&P.fast_q[e]);
+        const int code = nt_load(&P.fast_q[(size_t)P.ncap + e]);
+        uint32_t tile;
+        int isamp;
+        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        RegEmit H;
+        H.L = 0; H.minv_own = 0;
+        /* (one loop for both cases -- one copy of the chain code, 3400 instructions instead of 4800 -- was measured and is slower: 2.53
+           against 2.44 ms per launch pair; the shared loop keeps both lists alive) */
+        if (code >= 0) fast_chain_hits(S, chains[code], ray, H);       /* ONE chain can be touched: its list is the ray's hit list */
+        else {
+            /* several: the nearest first hit decides when every list starts ahead of the origin (see k_fast) */
+            const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
+            double t_best = RT_INFINITY, t_next = RT_INFINITY;
+            for (unsigned m = (unsigned)code & 0xFFu; m; m &= m - 1) {
+                const RtChain &ch = chains[S.root_fast[tl[__builtin_ctz(m)]]];
+                RegEmit T;
+                fast_chain_hits(S, ch, ray, T);
+                if (T.L == 0) continue;
+                const double t = T.h0.t;
+                if (!(t > 0.0)) { hand_over = true; break; }
+                if (t < t_best) { t_next = t_best; t_best = t; H.h0 = T.h0; H.minv_own = T.minv_own; H.L = 1; }
+                else if (t < t_next) t_next = t;
+            }
+            if (H.L == 1 && (t_next == t_best || !(S.mats[H.h0.mat].density > 0.0))) hand_over = true;
+        }
+        bool bail = false, final = false;
+        int pm = 0;
+        if (!hand_over) {
+            /* where the walk of Shade.cpp:424-516 stops: visual_walk<LITE>'s decisions, in its order */
+            int i = 0;
+            if (H.L > 0 && !(H.h0.t > 0.0)) { pm = H.h0.mat; i = 1; }
+            for (; i < H.L; i++) {
+                const HitRec hr = H.get(i);
+                if (hr.ntex) { bail = true; break; }                    /* (transform_normals<LITE>) */
+                const RtMaterialDev &mp = S.mats[pm];
+                if (mp.luster == RT_MAT_NOSHADE) { final = true; break; }
+                if (mp.prop) { bail = true; break; }
+                const RtMaterialDev &mh = S.mats[hr.mat];
+                if ((mp.refr != mh.refr) || (mh.luster != RT_MAT_TRANSPARENT)) {
+                    if (spectral_metal(mh.luster)) { bail = true; break; }
+                    boundary = true;
+                    bt = hr.t;
+                    bn = hr.n;                                          /* TransformNormals, Shade.cpp:264-284 */
+                    if (H.minv_own) bn = covec_mat(bn, H.minv_own);
+                    else for (int pa = (int)hr.leaf_affine - 1; pa >= 0; pa = S.affines[pa].link) bn = covec_mat(bn, S.affines[pa].minv);
+                    bids = pm | ((int)hr.mat << 16);
+                    bsurf = hr.surf;
+                    break;
+                }
+                pm = hr.mat;
+            }
+            if (!bail && !final && !boundary && S.mats[pm].prop) bail = true;      /* Shade.cpp:512-516: a propagating medium to infinity */
+            if (code < 0 && H.L == 1 && !bail && !boundary) hand_over = true;      /* the walk went on past the one hit that was kept */
+        }
+        if (hand_over) boundary = false;
+        else if (bail) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL); boundary = false; }
+        else if (!boundary) sample_deliver(S, k, final ? spec_load(S.mats[pm].color) : spec_const(0.0f), out_rgb, out_spec);
+    }
+    /* the record sits at the queue entry's own index (-1 = none): compacting the records would cost one same-address atomic per
+       64 rays -- measured: 560 k of them per launch made this kernel 1.6 x slower than all of k_fast -- and buys k_fast_shade the
+       quarter of its lanes whose rays had no boundary */
+    if (live) {
+        nt_store(&P.fr_k[e], boundary ? k : -1);
+        if (boundary) {
+            nt_store(&P.fr_t[e], bt);
+            d3_store(P.fr_n, P.ncap, 0, e, bn);
+            nt_store(&P.fr_ids[e], bids);
+            nt_store(&P.fr_ids[(size_t)P.ncap + e], bsurf);
+        }
+    }
+    const unsigned long long bh = __ballot(hand_over);
+    if (bh) {       /* root frames for the interpreter (k_visual runs behind the fast kernels) */
+        const int f = wave_alloc(hand_over ? 1 : 0, &P.counters[CTR_FRAMES]);
+        if (hand_over && f < P.fcap) {      /* rare: the ray is computed again rather than kept alive across the whole iteration */
+            double aux[6];
+            uint32_t tile;
+            int isamp;
+            const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+            fast_aux(S, isamp, aux);
+            root_frame(S, P, f, k, ray, aux, 0);
+        }
+    }
+  }
+}
+
+struct TwoHits {                /* "inside material a at t = 0" + the boundary hit, its normal already transformed */
+    HitRec h0, h1;
+    RT_DEV HitRec get(int i) const
+    {
+        HitRec r;
+        r.t = i ? h1.t : h0.t; r.n.x = i ? h1.n.x : h0.n.x; r.n.y = i ? h1.n.y : h0.n.y; r.n.z = i ? h1.n.z : h0.n.z;
+        r.leaf_affine = 0; r.surf = i ? h1.surf : h0.surf; r.mat = i ? h1.mat : h0.mat; r.prim = 0; r.ntex = 0; r.pad_ = 0; r.texpack = 0;
+        return r;
+    }
+    RT_DEV const double *own_minv() const { return 0; }
+};
+RT_DEV TwoHits fast_record(const RtPipe &P, const int e)
+{
+    TwoHits H;
+    const int ids = nt_load(&P.fr_ids[e]);
+    H.h0.t = 0.0; H.h0.n = d3(0.0, 0.0, 0.0); H.h0.mat = (uint16_t)(ids & 0xFFFF); H.h0.surf = 0;
+    H.h1.t = nt_load(&P.fr_t[e]);
+    H.h1.n = d3_fetch(P.fr_n, P.ncap, 0, e);
+    H.h1.mat = (uint16_t)((unsigned)ids >> 16);
+    H.h1.surf = (uint16_t)nt_load(&P.fr_ids[(size_t)P.ncap + e]);
+    return H;
+}
+template <int MODE>
+__global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTB_THREADS, 1) k_fast_shade(const RtDevScene Sv, RtSampleGrid g, RtPipe P, int64_t first, float *out_rgb, float *out_spec)
+{
+    RtDevScene SL = Sv;
+    if constexpr (MODE == 1) {
+        extern __shared__ double rt_dyn_lds[];
+        double *cur = rt_dyn_lds;
+        SL.blue = lds_stage(cur, Sv.blue, 2 * RT_BLUE_N);
+        SL.qi2 = lds_stage(cur, Sv.qi2, RT_BLUE_N);
+        SL.mats = lds_stage(cur, Sv.mats, Sv.n_mats);
+        SL.surfs = lds_stage(cur, Sv.surfs, Sv.n_surfs);
+        SL.lights = lds_stage(cur, Sv.lights, Sv.n_lights);
+        __syncthreads();
+    }
+    const RtDevScene &S = SL;
+    int n = P.counters[CTR_FAST];           /* one (possibly empty) record per entry of the fast queue */
+    if (n > P.ncap) n = P.ncap;
+    int *const work = &P.counters[CTR_WORK_F2];
+    const int wlane = threadIdx.x & 63;
+    /* waves claim RT_FAST_CLAIM entries per atomic.  The claims are not free -- k_fast's 280 k same-address atomics per launch (claims
+       of 128) cost it 0.55 of its 3.3 ms -- but dealing the chunks out statically (wave w takes chunks w, w + W, ...) was slower than
+       claims of 512: 2.65 against 2.44 ms per launch; the entries' costs differ enough for the balance to matter */
+  int wnext = 0, wlimit = 0;
+  for (;;) {
+    if (wnext >= wlimit) {
+        int b = 0;
+        if (wlane == 0) b = atomicAdd(work, RT_FAST_CLAIM);
+        b = __shfl(b, 0, 64);
+        if (b >= n) break;
+        wnext = b; wlimit = b + RT_FAST_CLAIM < n ? b + RT_FAST_CLAIM : n;
+    }
+    const int e = wnext + wlane;
+    wnext += 64;
+    const bool live = e < n;
+    int k = 0, n_shadow = 0;
+    bool need_frame = false;
+    if (live) k = nt_load(&P.fr_k[e]);
+    if (live && k >= 0) {
+        const TwoHits H = fast_record(P, e);
+        uint32_t tile;
+        int isamp;
+        double aux[6];
+        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        fast_aux(S, isamp, aux);
+        Walk B;
+        RegSink K;
+        visual_walk<true>(S, ray, aux, H, 2, B, K);
+        if (B.bail || !(B.flags & FR_BOUNDARY)) {       /* cannot happen: k_fast_hit found the boundary with the same tests */
+            atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL);
+        } else if (B.n_shadow > 0 || K.rough == RT_SURF_POLISHED) { need_frame = true; n_shadow = B.n_shadow; }
+        else {
+            const Spec R = light_loop(S, B.P, K.N, K.E, K.HN, K.F, K.rough, K.luster, K.color, B.R, aux[2], aux[3], 0u, [](int, Spec &) { return false; });
+            sample_deliver(S, k, R, out_rgb, out_spec);
+        }
+    }
+    /* The lanes that need shadow rays or children become traced level-0 frames (FR_TRACED) for k_shade, as in k_fast.  They walk
+       again, this time into the frame record itself (what the first walk found is not kept alive across the light loop of the
+       other lanes: that is what lets this kernel run at twice k_fast's occupancy). */
+    const unsigned long long bt = __ballot(need_frame);
+    if (bt == 0ull) continue;
+    const int f = wave_alloc(need_frame ? 1 : 0, &P.counters[CTR_FRAMES]);
+    const int base = wave_alloc(n_shadow, &P.counters[CTR_SHADOW]);
+    if (wlane == 0) atomicAdd(&P.counters[CTR_FAST + 1], __popcll(bt));
+    if (!need_frame || f >= P.fcap) continue;
+    {
+        const TwoHits H = fast_record(P, e);
+        uint32_t tile;
+        int isamp;
+        double aux[6];
+        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        fast_aux(S, isamp, aux);
+        aux_store(S, P, k, aux);
+        P.f_parent[f] = -1;
+        P.f_root[f] = k;
+        Walk B;
+        FrameSink FS = { P, f, FR_TRACED };
+        visual_walk<true>(S, ray, aux, H, 2, B, FS);
+        const int flags = frame_finish<true>(P, f, B, FS.flags);
+        P.f_ids[(size_t)IDS_SHBASE * P.fcap + f] = base;
+        P.f_ids[(size_t)IDS_SHMASK * P.fcap + f] = (int)B.mask;
+        P.f_flags[f] = flags;
+        if (B.n_shadow) shadow_append(S, P, B.P, B.mask, base, k, aux);
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ k_shadow: RayTracer::LightRay, Shade.cpp:301-359
  * shadow rays [0, n) (LITE) or those on the slow list (FULL) */
 /* ------------------------------------------------------------------ k_mesh_cross: the mesh walk in a kernel of its own
@@ -2372,6 +2661,8 @@ __global__ void __launch_bounds__(256) k_y4m_encode(const float *planes, int wid
 
 #if defined(RT_ONLY_FAST)     /* tools/kernel_usage.sh: a quick look at one kernel's registers without building the whole library */
 template __global__ void k_fast<1>(const RtDevScene, RtSampleGrid, RtPipe, int64_t, float *, float *);
+template __global__ void k_fast_hit<1>(const RtDevScene, RtSampleGrid, RtPipe, int64_t, float *, float *);
+template __global__ void k_fast_shade<1>(const RtDevScene, RtSampleGrid, RtPipe, int64_t, float *, float *);
 #elif defined(RT_ONLY_VISUAL)
 template __global__ void k_visual<true, 2, false>(const RtDevScene, RtPipe, int, int, int);
 template __global__ void k_visual<true, 1, true>(const RtDevScene, RtPipe, int, int, int);

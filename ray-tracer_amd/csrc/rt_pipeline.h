@@ -36,7 +36,8 @@ enum { CTR_FRAMES = 0 * CTR_LINE, CTR_OVERFLOW = 1 * CTR_LINE, CTR_SHADOW = 2 * 
        CTR_WORK_V = 5 * CTR_LINE, CTR_WORK_VS = 6 * CTR_LINE, CTR_WORK_S = 7 * CTR_LINE, CTR_WORK_SS = 8 * CTR_LINE, CTR_PROF = 9 * CTR_LINE,
        CTR_FAST = 10 * CTR_LINE, CTR_WORK_F = 11 * CTR_LINE, CTR_SNAP = 12 * CTR_LINE, CTR_WORK_SH = 13 * CTR_LINE,
        CTR_WORK_MV = 14 * CTR_LINE, CTR_WORK_MS = 15 * CTR_LINE,      /* k_mesh_cross over the visual / shadow slow list: cleared per level by the host */
-       CTR_COUNT = 16 * CTR_LINE };
+       CTR_WORK_F2 = 16 * CTR_LINE,         /* k_fast_shade's work counter */
+       CTR_COUNT = 17 * CTR_LINE };
 #define CTR_LEVEL_CLEAR (CTR_WORK_SS + 1 - CTR_SHADOW)     /* ints from CTR_SHADOW up to and including CTR_WORK_SS */
 #ifndef RT_CLAIM
 #define RT_CLAIM 128        /* items a persistent wave claims per atomic: two 64-item passes.  Same box, 4K / 64 spp: 512 / 256 / 128 / 64 items =
@@ -66,6 +67,12 @@ typedef struct RtPipe {
        recomputes the ray from the sample index, keeps the (at most three) hits in registers and, where no shadow ray or
        child ray is needed, shades and delivers the sample without ever making a frame.  2 x ncap ints: [k][chain]. */
     int    *fast_q;
+    /* the fast path in two kernels (option fast_split): k_fast_hit finds the boundary a fast ray's walk stops at and leaves a
+       44-byte record -- sample, distance, the hit's normal after the late transform, the materials on either side and the
+       surface -- for k_fast_shade, which recomputes the ray from the sample index and shades.  SoA over ncap entries, entry e
+       belongs to entry e of the fast queue: fr_k [1] (-1: that ray has no boundary), fr_t [1], fr_n [3], fr_ids [2] (material
+       before | material entered << 16; surface).  Null = one kernel. */
+    int    *fr_k; double *fr_t; double *fr_n; int *fr_ids;
     /* the mesh pre-walk (scenes with RtDevScene.mesh_pre_naff >= 0): for entry k of the slow list that the FULL kernel is
        about to work through, the triangle crossings of its ray with the scene's mesh -- mx_n[k] of them (-1: the walk ran out
        of stack, walk again in line), unsorted, crossing i at [i * mxcap + k]: distance and position in mesh_tris.  Written by

@@ -948,6 +948,11 @@ def test_fast_path_is_invisible(gpu, scene):
         assert np.array_equal(a, b), (w, h, spp)
         assert (sa.rays_primary, sa.rays_shadow, sa.rays_secondary) == (sb.rays_primary, sb.rays_shadow, sb.rays_secondary)
         assert sb.rays_fast == 0 and a.max() > 0
+        # the fast path as ONE kernel (k_fast) instead of two (k_fast_hit -> boundary record -> k_fast_shade, the default)
+        gpu.set_options({"fast_split": 0})
+        a1, s1 = fast_scene.render(w, h, spp, row0=r0, row1=r1)
+        gpu.set_options({"fast_split": 1})
+        assert np.array_equal(a1, a) and (s1.rays_fast, s1.rays_visual0, s1.rays_shadow, s1.rays_secondary) == (sa.rays_fast, sa.rays_visual0, sa.rays_shadow, sa.rays_secondary)
     assert (fast_total > 0) == (scene is not SCENE_FOG_PERSPECTIVE)     # the fog sphere encloses everything: every ray can touch it, and it is not eligible
     gpu.set_options({"level_sync": 1})              # the same passes with a host round trip per level
     c, sc = fast_scene.render(480, 270, 16)
