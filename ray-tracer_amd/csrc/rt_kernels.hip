@@ -2500,6 +2500,183 @@ __global__ void __launch_bounds__(256) k_splat_resample_rows(const RtDevScene Sv
     else { dst3[2 * rows * n_dst + o] = (float)sum0; dstw[o] = (float)sum1; }
 }
 
+/* The same, honouring the need map, with its tables in LDS and without the gather's idle lanes (option fuse_splat = 2, the default):
+   - tiles of the span that cannot matter (RtSampleGrid::tile_need) are neither gathered nor filtered: their pixels are the zeros the
+     two-kernel path would read, and a workgroup whose span holds no needed tile writes its zeros and leaves;
+   - the gather is a chain of dependent look-ups per splat (cell -> entry -> sample position -> colour) through tables of 58 KB that
+     do not stay in the vector L1: measured, 5.4 of this kernel's first 8.4 ms.  A supersample row only ever needs ONE row of cells of
+     the splat table (two on a tile's first and last row, for the neighbouring tile's overhang): those cells' offsets and entries --
+     with the sample's position spelled out, RtSplatEntry -- are staged in LDS (about 4 KB), and only the colour is read from memory;
+   - a thread per supersample pixel leaves lanes idle: the pixels of a row receive between none and ten splats (3.6 on average) and
+     the wave runs as long as its busiest lane.  The number of splats a pixel receives depends on its position within its 40 x 40
+     tile alone, so the lanes are dealt pixels of EQUAL position from different tiles of the span: thread u takes the pixel of rank
+     u / nn in the order `order[ly][.]` (positions of row ly of a tile, most splats first) of needed tile u % nn.
+   Same arithmetic and the same summation order as splat_pixel + k_resample_rows: bit-identical planes. */
+#define RT_FS_ROWENT 224        /* entries of one cell row the staging buffer holds, twice (the host checks: RtSplatTable::max_row_entries) */
+#define RT_FS_OFFS (RT_BLUE_NSQRT + 4)
+struct SplatRowLds { const int *off; const RtSplatEntry *ent; int cy1; };       /* off: [2][RT_FS_OFFS], already relative to ent; cy1: the second cell row (-99: none) */
+RT_DEV void splat_pixel_lds(const RtSampleGrid &g, const SplatRowLds &L, const float *sample_rgb, int px, int py, float &r, float &gg, float &b, float &w)
+{
+    r = 0.0f; gg = 0.0f; b = 0.0f; w = 0.0f;
+    const int tcx = px / RT_BLUE_NSQRT, tcy = py / RT_BLUE_NSQRT;
+    for (int tx = tcx - 1; tx <= tcx + 1; tx++) {
+        if (tx < 0 || tx >= g.tiles_x) continue;
+        const int lx = px - tx * RT_BLUE_NSQRT;
+        if (lx < -1 || lx > RT_BLUE_NSQRT) continue;
+        for (int ty = tcy - 1; ty <= tcy + 1; ty++) {
+            if (ty < g.tile_y0 || ty >= g.tile_y0 + g.tiles_y_local) continue;
+            const int ly = py - ty * RT_BLUE_NSQRT;
+            if (ly < -1 || ly > RT_BLUE_NSQRT) continue;
+            const int so = ly == L.cy1 ? RT_FS_OFFS : 0;       /* which staged cell row: ly is the row itself or cy1 by construction */
+            const int e0 = L.off[so + lx + 1], e1 = L.off[so + lx + 2];
+            const int tile = tx * g.tiles_y_local + (ty - g.tile_y0);
+            const int64_t sbase = (int64_t)tile * RT_BLUE_N;
+            const bool black = g.tile_mask && g.mask_skips_rgb && g.tile_mask[tile] == 0;
+            for (int e = e0; e < e1; e++) {
+                const RtSplatEntry en = L.ent[e];
+                /* v = g_rgvBlueNoise[i]*BLUE_NSQRT + vTile (Sampling.cpp:501), then FastSplatRGB's own arithmetic: as splat_pixel */
+                double x = en.bx + (double)tx * (double)RT_BLUE_NSQRT;
+                double y = en.by + (double)ty * (double)RT_BLUE_NSQRT;
+                x -= 0.5; y -= 0.5;
+                const double fx = floor(x), fy = floor(y);
+                const int i1 = (int)fx, j1 = (int)fy;
+                const double dx = x - fx, dy = y - fy;
+                double wx, wy;
+                if (px == i1) wx = 1.0 - dx; else if (px == i1 + 1) wx = dx; else continue;
+                if (py == j1) wy = 1.0 - dy; else if (py == j1 + 1) wy = dy; else continue;
+                w += (float)(wx * wy);
+                if (black) continue;
+                const float *c = sample_rgb + 3 * (sbase + en.i);
+                r += (float)((double)(float)((double)c[0] * wx) * wy);
+                gg += (float)((double)(float)((double)c[1] * wx) * wy);
+                b += (float)((double)(float)((double)c[2] * wx) * wy);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_splat_rows_need(RtSampleGrid g, RtSplatTable ST, const float *sample_rgb,
+                                                         int y0, int y1, int n_dst, RtTapTable T, float *dst3 /*[3][rows][n_dst]*/, float *dstw /*[rows][n_dst]*/)
+{
+    __shared__ float  s_px[4][RT_FS_SPAN + RT_FS_SPAN / 32 + 2];
+    __shared__ double s_taps[RT_RS_TAPS];
+    __shared__ RtSplatEntry s_ent[2 * RT_FS_ROWENT];
+    __shared__ int    s_off[2 * RT_FS_OFFS];
+    __shared__ unsigned char s_need[64];
+    __shared__ short  s_tiles[64];
+    __shared__ unsigned char s_ord[RT_BLUE_NSQRT];
+    const int id0 = blockIdx.x * RT_FS_DST, row = blockIdx.y, py = y0 + row, n_src = g.nW;
+    const int last = (id0 + RT_FS_DST - 1 < n_dst ? id0 + RT_FS_DST - 1 : n_dst - 1);
+    const int base = T.first[id0], span = T.first[last] + T.count[last] - base;      /* host: 0 < span <= RT_FS_SPAN */
+    const bool utaps = T.uniform && T.max_count <= RT_RS_TAPS;
+    const size_t rows = (size_t)(y1 - y0);
+    /* the pixels of the span that exist: [xa, xb]; the rest of the span repeats an edge pixel (WRAP_CLAMP) */
+    const int xa = base < 0 ? 0 : base, xe = base + span - 1, xb = xe >= n_src ? n_src - 1 : xe;
+    const int t0 = xa / RT_BLUE_NSQRT, nt = xb / RT_BLUE_NSQRT - t0 + 1;           /* <= 30 tiles */
+    const int tyl = py / RT_BLUE_NSQRT - g.tile_y0, ly = py - (py / RT_BLUE_NSQRT) * RT_BLUE_NSQRT;
+    const bool have_need = g.tile_need && tyl >= 0 && tyl < g.tiles_y_local;
+    const int id = id0 + (threadIdx.x & (RT_FS_DST - 1)), half = threadIdx.x >> 7;      /* planes 2 * half, 2 * half + 1 */
+    /* which tiles of the span can matter: one flag per tile, loaded by the first wave, compacted with a ballot */
+    int nn;
+    {
+        unsigned char v = 0;
+        if (threadIdx.x < nt) {
+            const int tx = t0 + (int)threadIdx.x;
+            v = (have_need && tx < g.tiles_x) ? g.tile_need[tx * g.tiles_y_local + tyl] : (unsigned char)1;
+        }
+        if (threadIdx.x < 64) {
+            const unsigned long long m = __ballot(v != 0);
+            s_need[threadIdx.x] = v;
+            if (v) s_tiles[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = (short)threadIdx.x;
+        }
+        nn = __syncthreads_count(v != 0);
+    }
+    if (nn == 0) {                      /* nothing in reach can matter: the zeros the filter would produce from zeros */
+        if (id < n_dst) {
+            const size_t o = (size_t)row * n_dst + id;
+            if (half == 0) { dst3[o] = 0.0f; dst3[rows * n_dst + o] = 0.0f; }
+            else { dst3[2 * rows * n_dst + o] = 0.0f; dstw[o] = 0.0f; }
+        }
+        return;
+    }
+    /* the cell rows this supersample row reads: its own, and the overhang row of the tile above (ly == 0) or below (ly == 39) */
+    SplatRowLds L;
+    L.off = s_off; L.ent = s_ent;
+    L.cy1 = ly == 0 ? RT_BLUE_NSQRT : (ly == RT_BLUE_NSQRT - 1 ? -1 : -99);
+    {
+        int at = 0;
+        for (int q = 0; q < (L.cy1 == -99 ? 1 : 2); q++) {
+            const int c0 = ((q ? L.cy1 : ly) + 1) * (RT_BLUE_NSQRT + 2);        /* first cell of the row: (cy + 1) * 42 + (cx + 1), cx = -1 */
+            const int eb = ST.offsets[c0], ee = ST.offsets[c0 + RT_BLUE_NSQRT + 2];
+            for (int k = threadIdx.x; k <= RT_BLUE_NSQRT + 2; k += 256) s_off[q * RT_FS_OFFS + k] = ST.offsets[c0 + k] - eb + at;
+            for (int k = threadIdx.x; k < ee - eb; k += 256) s_ent[at + k] = ST.entries_pos[eb + k];
+            at += ee - eb;
+        }
+    }
+    if (threadIdx.x < RT_BLUE_NSQRT) s_ord[threadIdx.x] = ST.order[ly * RT_BLUE_NSQRT + threadIdx.x];
+    for (int j = threadIdx.x; j < span; j += 256) {         /* zeros everywhere first: pixels of tiles that cannot matter stay zero */
+        const int q = RT_RS_IDX(j);
+        s_px[0][q] = 0.0f; s_px[1][q] = 0.0f; s_px[2][q] = 0.0f; s_px[3][q] = 0.0f;
+    }
+    if (utaps) {
+        const double *p0 = T.taps + T.offset[0];
+        for (int k = threadIdx.x; k < T.max_count; k += 256) s_taps[k] = p0[k];
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < nn * RT_BLUE_NSQRT; u += 256) {
+        const int rank = u / nn, k = s_tiles[u - rank * nn];
+        const int px = (t0 + k) * RT_BLUE_NSQRT + s_ord[rank];
+        if (px < xa || px > xb) continue;
+        float r, gg, b, w;
+#ifdef RT_RECON_DEBUG
+        if (g.pad_ & 2) { r = gg = b = w = 1.0f; } else
+#endif
+        splat_pixel_lds(g, L, sample_rgb, px, py, r, gg, b, w);
+        const int q = RT_RS_IDX(px - base);
+        s_px[0][q] = r; s_px[1][q] = gg; s_px[2][q] = b; s_px[3][q] = w;
+    }
+    __syncthreads();
+    if (base < 0 || xe >= n_src) {      /* WRAP_CLAMP at the image's edges */
+        for (int j = threadIdx.x; j < span; j += 256) {
+            const int is = base + j;
+            if ((unsigned)is < (unsigned)n_src) continue;
+            const int qs = RT_RS_IDX((is < 0 ? 0 : n_src - 1) - base), q = RT_RS_IDX(j);
+            s_px[0][q] = s_px[0][qs]; s_px[1][q] = s_px[1][qs]; s_px[2][q] = s_px[2][qs]; s_px[3][q] = s_px[3][qs];
+        }
+        __syncthreads();
+    }
+    if (id >= n_dst) return;
+    const int i0 = T.first[id], j0 = i0 - base, cnt = T.count[id];
+    const size_t o = (size_t)row * n_dst + id;
+    if (T.uniform && cnt > 0) {        /* a destination that reads zeros only: the zero it would compute */
+        const int a = (i0 < 0 ? 0 : (i0 >= n_src ? n_src - 1 : i0)) / RT_BLUE_NSQRT - t0, e = i0 + cnt - 1;
+        const int bq = (e < 0 ? 0 : (e >= n_src ? n_src - 1 : e)) / RT_BLUE_NSQRT - t0;
+        bool any = false;
+        for (int k = a; k <= bq; k++) any = any || s_need[k] != 0;
+        if (!any) {
+            if (half == 0) { dst3[o] = 0.0f; dst3[rows * n_dst + o] = 0.0f; }
+            else { dst3[2 * rows * n_dst + o] = 0.0f; dstw[o] = 0.0f; }
+            return;
+        }
+    }
+    const double *pf = T.taps + T.offset[id];
+    double sum0 = 0.0, sum1 = 0.0, wsum = 0.0;
+    const float *a0 = s_px[2 * half], *a1 = s_px[2 * half + 1];
+#ifdef RT_RECON_DEBUG
+    if (!(g.pad_ & 1))
+#endif
+    for (int k = 0; k < cnt; k++) {
+        const double fw = utaps ? s_taps[k] : pf[k];
+        const int q = RT_RS_IDX(j0 + k);
+        sum0 += fw * (double)a0[q];
+        sum1 += fw * (double)a1[q];
+        if (!T.uniform) wsum += fw;
+    }
+    if (T.uniform) wsum = T.wsum_uniform;
+    if (wsum != 0.0) { sum0 /= wsum; sum1 /= wsum; }
+    if (half == 0) { dst3[o] = (float)sum0; dst3[rows * n_dst + o] = (float)sum1; }
+    else { dst3[2 * rows * n_dst + o] = (float)sum0; dstw[o] = (float)sum1; }
+}
+
 /* vertical pass: src [planes][src_rows_local][width] (rows src_y0..), dst rows [row0,row1) of [planes][H][width] */
 __global__ void __launch_bounds__(256) k_resample_cols(const float *src, int planes, int src_rows_local, int src_y0, int n_src_total, int width,
                                                        int row0, int row1, RtTapTable T, float *dst, size_t dst_plane_stride,

@@ -141,9 +141,16 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
     double  inv_size;                   /* 1 / size, for the approximate (culling-only) sample position */
 } RtSampleGrid;
 
+typedef struct RtSplatEntry { double bx, by; int i, pad_; } RtSplatEntry;      /* a candidate sample: g_rgvBlueNoise[i] * BLUE_NSQRT (both coordinates) and i */
 typedef struct RtSplatTable {   /* contributors of each pixel of a (40+2)^2 tile neighbourhood, CSR */
     const int *offsets;         /* 42*42 + 1 */
     const int *entries;         /* candidate sample indices, ascending = the reference's splat order */
+    /* for k_splat_rows_need, which stages the one or two cell rows a supersample row needs in LDS: the same entries with the sample's
+       position in the tile spelled out (no second look-up), the positions of every tile row ordered by the number of splats they
+       receive (most first) [40][40], and the largest number of entries a cell row holds */
+    const RtSplatEntry *entries_pos;
+    const unsigned char *order;
+    int max_row_entries, pad_;
 } RtSplatTable;
 
 typedef struct RtTapTable {     /* ComputeTaps / Resample, Sampling.cpp:86-184 */

@@ -493,22 +493,24 @@ def test_jitter_tile_matches_oracle(gpu, oracle, scene, tol):
     assert np.array_equal(band[:, 17:41, :], img[:, 17:41, :])
 
 
-def test_fused_splat_and_row_filter_equals_two_kernels(gpu):
-    """k_splat_resample_rows (gather + horizontal filter through LDS, no supersampled image in memory) gives the bits of
-    k_splat_gather + k_resample_rows: integer and fractional decimation ratios, upsampling, bands, widths that are not a
-    multiple of the workgroup's 128 destinations."""
-    L = gpu.rt_lib()
-    fs = gpu.FrontScene("S1", "fastblue", optimize=True)
+@pytest.mark.parametrize("scene", ["S1", "S0"])
+def test_fused_splat_and_row_filter_equals_two_kernels(gpu, scene):
+    """The fused reconstruction kernels (gather + horizontal filter through LDS, no supersampled image in memory) give the bits of
+    k_splat_gather + k_resample_rows: integer and fractional decimation ratios, upsampling, bands, widths that are not a multiple
+    of the workgroup's 128 destinations.  fuse_splat = 2 (the default: k_splat_rows_need, which honours the need map and deals
+    equal tile positions to a wave's lanes) under every mode of the need map -- S0 has tiles that cannot matter, S1's floor
+    fills the frame -- and fuse_splat = 1 (the first fused kernel, no need map) against the two kernels."""
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
     g = gpu.GpuScene(fs.desc)
-    try:
-        for (w, h, spp, r0, r1) in ((130, 75, 4, 0, 0), (64, 64, 1.5, 20, 41), (333, 17, 2, 0, 0), (50, 300, 9, 100, 130), (300, 40, 64, 0, 0), (97, 31, 0.5, 0, 0)):
-            L.rt_set_option(b"fuse_splat", 1)
+    for (w, h, spp, r0, r1) in ((130, 75, 4, 0, 0), (64, 64, 1.5, 20, 41), (333, 17, 2, 0, 0), (50, 300, 9, 100, 130), (300, 40, 64, 0, 0), (97, 31, 0.5, 0, 0),
+                                (960, 540, 16, 0, 0), (960, 540, 16, 200, 330)):
+        gpu.set_options({"fuse_splat": 0, "tile_need": 0})
+        ref, _ = g.render(w, h, spp, row0=r0, row1=r1)
+        assert ref.max() > 0
+        for fuse, need in ((2, 3), (2, 2), (2, 1), (2, 0), (1, 3), (0, 3)):
+            gpu.set_options({"fuse_splat": fuse, "tile_need": need})
             a, _ = g.render(w, h, spp, row0=r0, row1=r1)
-            L.rt_set_option(b"fuse_splat", 0)
-            b, _ = g.render(w, h, spp, row0=r0, row1=r1)
-            assert np.array_equal(a, b), (w, h, spp)
-    finally:
-        L.rt_set_option(b"fuse_splat", 0)
+            assert np.array_equal(a, ref), (w, h, spp, fuse, need)
 
 
 @pytest.mark.parametrize("scene", ["S0", "S1", SCENE_ROW, SCENE_FOG_PERSPECTIVE, SCENE_FOG_ORTHOGRAPHIC])
