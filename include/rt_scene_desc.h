@@ -61,8 +61,25 @@ enum RtTextureId {
     RT_TEX_VORONOIANTIBUMP = 14, RT_TEX_VORONOICRINKLED = 15,
     /* solid colour textures (TextureMaps.cpp:518-700) and SeaScape (:497-513, which has no effect on the hit) */
     RT_TEX_VORONOI = 16, RT_TEX_AGATE = 17, RT_TEX_MARBLE = 18, RT_TEX_CLOUDS = 19, RT_TEX_WOOD = 20, RT_TEX_SPOTS = 21,
-    RT_TEX_VEINS = 22, RT_TEX_SEASCAPE = 23, RT_TEX__COUNT
+    RT_TEX_VEINS = 22, RT_TEX_SEASCAPE = 23,
+    /* the planet image maps (PlanetMapping, TextureMaps.cpp:955-1084, through the wrappers :1098-1243): colour map, bump map and
+       water mask come from RtSceneDesc.images, by the slots of RtImageSlot */
+    RT_TEX_EARTH = 24, RT_TEX_EARTH2 = 25, RT_TEX_MARS = 26, RT_TEX_MOON = 27, RT_TEX_VENUS = 28, RT_TEX_MERCURY = 29, RT_TEX_SKY = 30,
+    RT_TEX__COUNT
 };
+/* The images PlanetMapping reads, one slot per file-static Image of TextureMaps.cpp:945-947 (file names: :1093-1230). */
+enum RtImageSlot {
+    RT_IMG_SKY = 0, RT_IMG_EARTH = 1, RT_IMG_EARTHBUMP = 2, RT_IMG_EARTHWATER = 3, RT_IMG_MARS = 4, RT_IMG_MARSBUMP = 5,
+    RT_IMG_MOON = 6, RT_IMG_MOONBUMP = 7, RT_IMG_VENUS = 8, RT_IMG_VENUSBUMP = 9, RT_IMG_MERCURY = 10, RT_IMG_MERCURYBUMP = 11,
+    RT_IMG__COUNT = 12
+};
+enum { RT_WRAP_CLAMP = 0, RT_WRAP_AROUND = 1, RT_WRAP_MIRROR = 2 };        /* Image.h:17-19 */
+typedef struct RtImageMap {         /* an Image (Image.h:140-156) as ReadBMP leaves it: linear floats, plane after plane, row 0 = top */
+    int32_t width, height, channels;        /* channels: 1 or 3 */
+    int32_t wrap_x, wrap_y;                 /* m_bWrapX, m_bWrapY */
+    int32_t pad_;
+    const float *pixels;                    /* [channels][height][width]; null = this slot was not loaded */
+} RtImageMap;
 /* Propagator function pointers (Solids.h:267); 0 = none. */
 enum RtPropagatorId { RT_PROP_NONE = 0, RT_PROP_COLOREDGLASS = 1, RT_PROP_FOGGY = 2, RT_PROP_ATMOSPHERE = 3, RT_PROP__COUNT };
 
@@ -120,6 +137,9 @@ typedef struct RtSceneDesc {
     float          ambient_flux[RT_NSPEC];
     RtCamera       camera;
     RtSampler      sampler;
+    int32_t        n_images;        /* 0, or RT_IMG__COUNT when a planet texture is used */
+    int32_t        pad_;
+    const RtImageMap *images;       /* indexed by RtImageSlot */
 } RtSceneDesc;
 
 typedef struct RtRenderDesc {

@@ -73,6 +73,11 @@ extern "C" int orc_load_tables(const char *path)
     memcpy(&g_t.blue[0], &blob[off], sizeof(double) * cnt);
     if (!load_spec(blob, "g_sGreen", g_t.s_green) || !load_spec(blob, "g_sEqualWhite", g_t.s_white) || !load_spec(blob, "g_sOrange", g_t.s_orange) ||
         !load_spec(blob, "g_sRed", g_t.s_red) || !load_spec(blob, "g_sBlue", g_t.s_blue)) return -7;
+    {   /* PlanetMapping's spectra: g_sWhite, g_sD6500 (RGBtoSpectrum) and s_sOcean (TextureMaps.cpp:1123) */
+        Spec cyan;
+        if (!load_spec(blob, "g_sWhite", g_t.s_gwhite) || !load_spec(blob, "g_sD6500", g_t.s_d6500) || !load_spec(blob, "g_sCyan", cyan)) return -8;
+        g_t.s_ocean = g_t.s_white * 0.20 + cyan * 0.20 + g_t.s_blue * 0.30;
+    }
     if (!find_table(blob, "DiskSamples128", dt, cnt, off) || dt != 1 || cnt != 256) return -6;
     g_t.disk128.resize(cnt);
     memcpy(&g_t.disk128[0], &blob[off], sizeof(double) * cnt);
@@ -214,6 +219,18 @@ extern "C" void *orc_scene_create(const RtSceneDesc *d, int run_optimize)
             break;
         default: break;
         }
+    }
+    if (d->n_images == RT_IMG__COUNT && d->images) {
+        s->images.assign(d->images, d->images + RT_IMG__COUNT);
+        s->image_px.resize(RT_IMG__COUNT);
+        for (int k = 0; k < RT_IMG__COUNT; k++) {
+            RtImageMap &m = s->images[k];
+            if (!m.pixels) continue;
+            s->image_px[k].assign(m.pixels, m.pixels + (size_t)m.width * m.height * m.channels);
+            m.pixels = &s->image_px[k][0];
+        }
+        for (int i = 0; i < d->n_nodes; i++)
+            if (s->nodes[i]->type == RT_NODE_MATERIAL || s->nodes[i]->type == RT_NODE_SURFACE) s->nodes[i]->images = &s->images[0];
     }
     s->root = d->root >= 0 ? s->nodes[d->root] : 0;
     if (run_optimize && s->root)

@@ -231,7 +231,7 @@ static void transform_normals(Hit &h, const Ctx &cx)
     Node *pa;
     for (pa = h.affine; pa; pa = pa->link) {
         while (it < h.tex.size() && h.tex[it].pa == pa) {
-            apply_texture(h.tex[it].tex, h.tex[it].p, h, cx);
+            apply_texture(h.tex[it].tex, h.tex[it].p, h, cx, h.tex[it].images);
             it++;
         }
         h.n = mul(h.n, pa->mi);
@@ -239,7 +239,7 @@ static void transform_normals(Hit &h, const Ctx &cx)
             h.np = mul(h.np, pa->mi);
     }
     while (it < h.tex.size() && h.tex[it].pa == pa) {       /* pa == 0 here */
-        apply_texture(h.tex[it].tex, h.tex[it].p, h, cx);
+        apply_texture(h.tex[it].tex, h.tex[it].p, h, cx, h.tex[it].images);
         it++;
     }
 }

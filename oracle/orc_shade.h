@@ -24,6 +24,8 @@ struct Scene {
     std::vector<int> qi2, qi3;
     double  aux_init[6];
     uint32_t prng_x, prng_c;    /* MWC state at Render time (JitterSamplingTile) */
+    std::vector<std::vector<float> > image_px;      /* own copies of RtSceneDesc.images */
+    std::vector<RtImageMap> images;
     Scene() : root(0), has_ambient(false), sampler_type(0), venera(0), prng_x(886459), prng_c(361290869) {}
     ~Scene() { for (size_t i = 0; i < nodes.size(); i++) delete nodes[i]; }
 };
@@ -36,6 +38,7 @@ struct Tables {
     Spec  chan[3];                      /* g_sRedChannel, g_sGrnChannel, g_sBluChannel */
     std::vector<double> blue;           /* g_rgvBlueNoise, 1600 x 2 */
     std::vector<double> disk128;        /* DiskSamples128, 128 x 2 (LowDiscrepancy.cpp:129) */
+    Spec  s_gwhite, s_d6500, s_ocean;                 /* g_sWhite, g_sD6500, s_sOcean: the planet image maps */
     Spec  s_green, s_white, s_orange, s_red, s_blue;  /* g_sGreen, g_sEqualWhite, g_sOrange, g_sRed, g_sBlue: the solid colour textures' palette */
     Tables() : loaded(false) {}
 };
@@ -46,7 +49,7 @@ float gradient_band_noise(float *g, const float *p, int ndim);
 float gradient_voronoi(float *grad, const float *p, int npow);
 float fractal_noise_export(const float *p, int ndim, int levels, int absolute);    /* FractalNoise, Texture.cpp:200-241 */
 void  fresnel_probe(double fNE, double n1, double n2, int metal_luster, double *F, double *fNT, float *spec10);    /* Shade.cpp:90-153 */
-void  apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx);
+void  apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx, const RtImageMap *images = 0);
 void  transform_normals_export(Hit &h, const Ctx &cx);   /* TransformNormals, Shade.cpp:264-284 */
 
 Ray  camera_emit(const RtCamera &c, double vx, double vy, const Ctx &cx);

@@ -599,7 +599,7 @@ void node_hits(Node *n, const Ray &ray, Ctx &cx, HitList &out)
             Hit &h = out[i];
             if (h.mat->density > 0.0) {
                 h.mat = n;
-                if (n->i1) { TexRef t; t.p = at(ray, h.t); t.tex = n->i1; t.pa = n->link; h.tex.push_back(t); }
+                if (n->i1) { TexRef t; t.p = at(ray, h.t); t.tex = n->i1; t.pa = n->link; t.images = n->images; h.tex.push_back(t); }
             }
         }
         return;
@@ -610,7 +610,7 @@ void node_hits(Node *n, const Ray &ray, Ctx &cx, HitList &out)
             Hit &h = out[i];
             if (h.t == 0.0) continue;
             h.surf = n;
-            if (n->i1) { TexRef t; t.p = at(ray, h.t); t.tex = n->i1; t.pa = n->link; h.tex.push_back(t); }
+            if (n->i1) { TexRef t; t.p = at(ray, h.t); t.tex = n->i1; t.pa = n->link; t.images = n->images; h.tex.push_back(t); }
         }
         return;
     }

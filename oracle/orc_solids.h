@@ -26,6 +26,7 @@ struct TexRef {                 /* TextureList, Solids.h:295-303 */
     V3    p;                    /* ray(t) in the coordinates of the node that queued it */
     int   tex;                  /* RtTextureId */
     Node *pa;                   /* affine level at which it fires */
+    const RtImageMap *images;   /* the scene's planet image maps (RtSceneDesc.images), for the PlanetMapping call-outs */
 };
 struct Hit {                    /* RayTracer2020.h:108-132 */
     double  t;
@@ -78,8 +79,9 @@ struct Node {
     /* material */
     double  density, refr;
     Spec    color;
+    const RtImageMap *images;   /* material / surface: the scene's planet image maps, 0 = none */
     Node() : type(0), id(-1), index(-1), left(0), right(0), i0(0), i1(0), i2(0), link(0),
-             P(0), Q(0), R(0), Rneck(0), minor(0), density(0), refr(1) {}
+             P(0), Q(0), R(0), Rneck(0), minor(0), density(0), refr(1), images(0) {}
 };
 
 /* g_mVacuum / g_mNeutronium / s_sMatte: Solids.cpp:1463-1464, 169 */

@@ -273,6 +273,157 @@ static void perturb(Hit &h, const V3 &d)
     }
 }
 
+/* ---- the planet image maps ---- */
+static int img_wrap(int i, int len, int wrap)                   /* ML_Modulus, ML_Wrap: Image.cpp:50-83 */
+{
+    if (wrap == RT_WRAP_AROUND) { i = i % len; if (i < 0) i += len; return i; }
+    if (wrap == RT_WRAP_MIRROR) { i = i % (2 * len); if (i < 0) i += 2 * len; if (i >= len) i = 2 * len - i - 1; return i; }
+    return i < 0 ? 0 : (i >= len ? len - 1 : i);
+}
+static float img_get(const RtImageMap &im, int i, int j, int k)  /* Image::Get, Image.h:226-236 */
+{
+    if ((unsigned)i >= (unsigned)im.width || (unsigned)j >= (unsigned)im.height) { i = img_wrap(i, im.width, im.wrap_x); j = img_wrap(j, im.height, im.wrap_y); }
+    return im.pixels[(size_t)i + (size_t)im.width * ((size_t)j + (size_t)im.height * (size_t)k)];
+}
+static double img_sample_lerp(const RtImageMap &im, double x, double y, int k = 0)      /* Image.cpp:1262-1283 */
+{
+    x -= 0.5; y -= 0.5;
+    const int i1 = (int)(long long)floor(x), j1 = (int)(long long)floor(y);     /* unsigned(floor(x)) handed to Get(int ...) */
+    const double dx = x - floor(x), dy = y - floor(y);
+    double a = img_get(im, i1, j1, k), b = img_get(im, i1 + 1, j1, k), c = img_get(im, i1, j1 + 1, k), d = img_get(im, i1 + 1, j1 + 1, k);
+    a = a + dx * (b - a);
+    c = c + dx * (d - c);
+    return double(a + dy * (c - a));
+}
+struct Rgb3 { float r, g, b; };
+static Rgb3 img_get_rgb(const RtImageMap &im, int i, int j)       /* Image::GetRGB, Image.h:266-281 */
+{
+    Rgb3 c;
+    if (im.channels < 3) { c.r = c.g = c.b = img_get(im, i, j, 0); return c; }
+    c.r = img_get(im, i, j, 0); c.g = img_get(im, i, j, 1); c.b = img_get(im, i, j, 2);
+    return c;
+}
+/* DisplayRGB arithmetic, Image.h:64-69 */
+static Rgb3 rgb_add(const Rgb3 &a, const Rgb3 &b) { Rgb3 c = { float(double(a.r + b.r)), float(double(a.g + b.g)), float(double(a.b + b.b)) }; return c; }
+static Rgb3 rgb_sub(const Rgb3 &a, const Rgb3 &b) { Rgb3 c = { float(double(a.r - b.r)), float(double(a.g - b.g)), float(double(a.b - b.b)) }; return c; }
+static Rgb3 rgb_mul(const Rgb3 &a, double f) { Rgb3 c = { float(a.r * f), float(a.g * f), float(a.b * f) }; return c; }
+static Rgb3 img_sample_lerp_rgb(const RtImageMap &im, double x, double y)                /* Image.cpp:1285-1307 */
+{
+    x -= 0.5; y -= 0.5;
+    const int i1 = (int)(long long)floor(x), j1 = (int)(long long)floor(y);
+    const double dx = x - floor(x), dy = y - floor(y);
+    Rgb3 a = img_get_rgb(im, i1, j1), b = img_get_rgb(im, i1 + 1, j1), c = img_get_rgb(im, i1, j1 + 1), d = img_get_rgb(im, i1 + 1, j1 + 1);
+    a = rgb_add(a, rgb_mul(rgb_sub(b, a), dx));
+    c = rgb_add(c, rgb_mul(rgb_sub(d, c), dx));
+    return rgb_add(a, rgb_mul(rgb_sub(c, a), dy));
+}
+static void img_sample_gradient(const RtImageMap &im, double x, double y, float g[2])  /* Image.h:187-189 */
+{
+    g[0] = float(img_sample_lerp(im, x + 0.5, y) - img_sample_lerp(im, x - 0.5, y));
+    g[1] = float(img_sample_lerp(im, x, y + 0.5) - img_sample_lerp(im, x, y - 0.5));
+}
+static Spec rgb_to_spectrum_6500(const Rgb3 &rgb)                /* RGBtoSpectrum(rgb, 1), RadiometryColor.cpp:947-963 */
+{
+    Spec s;
+    if (rgb.r < rgb.g && rgb.r < rgb.b) s = g_t.s_gwhite * rgb.r + g_t.s_green * (rgb.g - rgb.r) + g_t.s_blue * (rgb.b - rgb.r);
+    else if (rgb.g < rgb.r && rgb.g < rgb.b) s = g_t.s_gwhite * rgb.g + g_t.s_red * (rgb.r - rgb.g) + g_t.s_blue * (rgb.b - rgb.g);
+    else s = g_t.s_gwhite * rgb.b + g_t.s_red * (rgb.r - rgb.b) + g_t.s_green * (rgb.g - rgb.b);
+    for (int i = 0; i < NSPEC; i++) s.v[i] = g_t.s_d6500.v[i] ? s.v[i] / g_t.s_d6500.v[i] : 0.0f;      /* Spectrum / Spectrum, RadiometryColor.h:34-42 */
+    return s;
+}
+static void perturb(Hit &h, const V3 &d);
+/* PlanetMapping, TextureMaps.cpp:955-1084, with its callers' images (:1098-1243).  The writes to the shared Material / Surface go to
+   private copies, as for the solid colour textures (Q13).  Q15: without a bump map the reference hands three uninitialised
+   doubles to PerturbNormal (:1055-1083, the sky dome): here the normal is left alone. */
+static void planet_texture(int tex, const V3 &p, Hit &h, const Ctx &cx, const RtImageMap *images)
+{
+    static const int slots[7][3] = { { RT_IMG_EARTH, RT_IMG_EARTHBUMP, RT_IMG_EARTHWATER }, { RT_IMG_EARTH, RT_IMG_EARTHBUMP, -1 }, { RT_IMG_MARS, RT_IMG_MARSBUMP, -1 },
+                                     { RT_IMG_MOON, RT_IMG_MOONBUMP, -1 }, { RT_IMG_VENUS, RT_IMG_VENUSBUMP, -1 }, { RT_IMG_MERCURY, RT_IMG_MERCURYBUMP, -1 }, { RT_IMG_SKY, -1, -1 } };
+    if (!images) return;
+    const int *sl = slots[tex - RT_TEX_EARTH];
+    const RtImageMap *pimColor = &images[sl[0]], *pimBump = sl[1] >= 0 ? &images[sl[1]] : 0, *pimWater = sl[2] >= 0 ? &images[sl[2]] : 0;
+    double fLat, fLong, w, x, y, z, r, fScale, fKmPerPixel, fSinLat, fCosLat, fSinLong, fCosLong;
+    double xGrad, yGrad, zGrad, xNormal, yNormal, zNormal;
+    float rgfGrad[2];
+    int bPolar;
+    const V3 cvN = normalize(h.n);
+    x = cvN.x; y = cvN.y; z = cvN.z;
+    fLat = asin(z);
+    fLong = kPi - atan2(p.y, p.x);
+    w = 8192.0;                                     /* SPHEREMAPWIDTH */
+    fKmPerPixel = 2.0 * kPi * 6378.137 / w;
+    if (fLong < 0.0) fLong += 2.0 * kPi;
+    fSinLat = z;
+    fCosLat = sqrt(1.0 - z * z);
+    r = sqrt(x * x + y * y);
+    fSinLong = y / r;
+    fCosLong = x / r;
+    if (fabs(fLat * 180.0 / kPi) > 32.70) {         /* MAPSELECT */
+        double xPolar, yPolar, fScalePolar;
+        if (fabs(fLat) < 0.5 * kPi - 0.001) fScalePolar = (0.5 * kPi - fabs(fLat)) / r;
+        else fScalePolar = 1 / fabs(z);
+        if (fLat > 0.0) {
+            xPolar = +x / (1.0 + z) / kPi + 0.25;
+            yPolar = +y / (1.0 + z) / kPi + 0.25;
+            if (xPolar < 0.0 || xPolar >= 0.5) fScalePolar = 0.0;
+        } else {
+            xPolar = +x / (1.0 - z) / kPi + 0.75;
+            yPolar = -y / (1.0 - z) / kPi + 0.25;
+            if (xPolar < 0.5 || xPolar >= 1.0) fScalePolar = 0.0;
+        }
+        if (yPolar < 0.0 || yPolar >= 0.5) fScalePolar = 0.0;
+        x = xPolar; y = yPolar; fScale = fScalePolar; bPolar = 1;
+    } else {
+        double xCyl = fLong / (2.0 * kPi), fScaleCyl;
+        if (xCyl >= 1.0) xCyl -= 1.0; else if (xCyl < 0.0) xCyl += 1.0;
+        const double yCyl = -log(tan(0.25 * kPi + 0.5 * fLat)) / (2.0 * kPi) + 0.75;
+        if (yCyl >= 0.5 && yCyl < 1.0) fScaleCyl = 1.0 / r; else fScaleCyl = 0.0;
+        x = xCyl; y = yCyl; fScale = fScaleCyl; bPolar = 0;
+    }
+    Node *m = cx.clone_material(h.mat);
+    h.mat = m;
+    if (pimWater && img_sample_lerp(*pimWater, w * x, w * y) > 0.0) {
+        m->color = g_t.s_ocean;
+        h.surf = cx.clone_material(h.surf ? h.surf : &g_b.matte); h.surf->i0 = RT_SURF_SHINY;
+        img_sample_gradient(*pimWater, w * x, w * y, rgfGrad);
+        xGrad = rgfGrad[0] * 256.0 * fScale / fKmPerPixel;
+        yGrad = rgfGrad[1] * 256.0 * fScale / fKmPerPixel;
+        zGrad = 1.0;
+    } else {
+        m->color = rgb_to_spectrum_6500(img_sample_lerp_rgb(*pimColor, w * x, w * y));
+        if (pimBump) {
+            h.surf = cx.clone_material(h.surf ? h.surf : &g_b.matte); h.surf->i0 = RT_SURF_SHINY;
+            img_sample_gradient(*pimBump, w * x, w * y, rgfGrad);
+            xGrad = rgfGrad[0] * 256.0 * fScale / fKmPerPixel;
+            yGrad = rgfGrad[1] * 256.0 * fScale / fKmPerPixel;
+            zGrad = 0.0;
+        } else {
+            m->i0 = RT_MAT_NOSHADE;
+            return;                                 /* Q15 */
+        }
+    }
+    if (bPolar) {
+        x = +fCosLong * xGrad - -fSinLong * yGrad;
+        y = -fSinLong * xGrad + +fCosLong * yGrad;
+        z = zGrad;
+        xNormal = fCosLat * z - fSinLat * x;
+        yNormal = y;
+        zNormal = fSinLat * z + fCosLat * x;
+        x = fCosLong * xNormal - fSinLong * yNormal;
+        y = fSinLong * xNormal + fCosLong * yNormal;
+        z = zNormal;
+    } else {
+        y = xGrad;
+        x = fCosLat * zGrad - fSinLat * yGrad;
+        z = fSinLat * zGrad + fCosLat * yGrad;
+        zNormal = z;
+        xNormal = fCosLong * x - fSinLong * y;
+        yNormal = fSinLong * x + fCosLong * y;
+        z = zNormal; x = xNormal; y = yNormal;
+    }
+    perturb(h, V3(x, y, z));
+}
+
 static void bump3(const V3 &p, Hit &h, double scale)      /* Bumpy / MicroFacets / MicroFacets2: TextureMaps.cpp:209-249 */
 {
     float q[3] = { float(p.x * scale), float(p.y * scale), float(p.z * scale) }, g[3];
@@ -282,9 +433,11 @@ static void bump3(const V3 &p, Hit &h, double scale)      /* Bumpy / MicroFacets
 
 extern const V3 kDodecahedronNormals[20];
 
-void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx)
+void apply_texture(int tex, const V3 &p, Hit &h, const Ctx &cx, const RtImageMap *images)
 {
     switch (tex) {
+    case RT_TEX_EARTH: case RT_TEX_EARTH2: case RT_TEX_MARS: case RT_TEX_MOON: case RT_TEX_VENUS: case RT_TEX_MERCURY: case RT_TEX_SKY:
+        planet_texture(tex, p, h, cx, images); return;
     case RT_TEX_VORONOI: case RT_TEX_AGATE: case RT_TEX_MARBLE: case RT_TEX_CLOUDS: case RT_TEX_WOOD: case RT_TEX_SPOTS: case RT_TEX_VEINS:
         colour_texture(tex, p, h, cx); return;
     case RT_TEX_SEASCAPE:     return;       /* TextureMaps.cpp:497-513: the loop computes points and discards them */

@@ -38,11 +38,17 @@ class RtSampler(C.Structure):
                 ("qindex3", C.POINTER(C.c_int32)), ("aux_init", C.c_double * 6), ("prng_x", C.c_uint32), ("prng_c", C.c_uint32)]
 
 
+class RtImageMap(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("wrap_x", C.c_int32), ("wrap_y", C.c_int32),
+                ("pad_", C.c_int32), ("pixels", C.POINTER(C.c_float))]
+
+
 class RtSceneDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("root", C.c_int32), ("nodes", C.POINTER(RtNode)),
                 ("n_data", C.c_int32), ("n_lights", C.c_int32), ("data", C.POINTER(C.c_double)),
                 ("lights", C.POINTER(RtLight)), ("has_ambient", C.c_int32), ("ambient_flux", C.c_float * NSPEC),
-                ("camera", RtCamera), ("sampler", RtSampler)]
+                ("camera", RtCamera), ("sampler", RtSampler),
+                ("n_images", C.c_int32), ("pad_", C.c_int32), ("images", C.POINTER(RtImageMap))]
 
 
 class RtRenderDesc(C.Structure):
@@ -298,6 +304,46 @@ def clip_planes(half, table, from_origin):
     if L.rtf_clip_planes(float(half), table.encode(), float(from_origin), _p(out, C.c_double)):
         raise RtError(L.rtf_last_error().decode())
     return out
+
+
+def set_asset_path(directory):
+    """SetAssetPath of the front end: where the planet image maps (EarthColorMap.bmp, ...) are read from; None = RT_AMD_ASSETS."""
+    L = frontend_lib()
+    L.rtf_set_asset_path.argtypes = [C.c_char_p]
+    L.rtf_set_asset_path.restype = None
+    L.rtf_set_asset_path(directory.encode() if directory else None)
+
+
+class BmpImage(object):
+    """Image::ReadBMP of the front end (Image.cpp:95-288): .planes is [channels][H][W] linear floats, row 0 = top; get() reads one
+    pixel through Image::Get with the given wrap modes (Image.cpp:50-89)."""
+
+    def __init__(self, path, gamma=-1.0):
+        L = frontend_lib()
+        L.rtf_image_read_bmp.argtypes = [C.c_char_p, C.c_double, C.POINTER(C.c_int)]
+        L.rtf_image_read_bmp.restype = C.c_void_p
+        L.rtf_image_planes.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.rtf_image_planes.restype = None
+        L.rtf_image_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rtf_image_get.restype = C.c_float
+        L.rtf_image_free.argtypes = [C.c_void_p]
+        L.rtf_image_free.restype = None
+        whc = (C.c_int * 3)()
+        self._L = L
+        self.h = L.rtf_image_read_bmp(path.encode(), float(gamma), whc)
+        if not self.h:
+            raise RtError(L.rtf_last_error().decode())
+        self.width, self.height, self.channels = int(whc[0]), int(whc[1]), int(whc[2])
+        self.planes = np.zeros((self.channels, self.height, self.width), dtype=np.float32)
+        L.rtf_image_planes(self.h, _p(self.planes, C.c_float))
+
+    def get(self, i, j, k=0, wrap_x=2, wrap_y=2):
+        return float(self._L.rtf_image_get(self.h, wrap_x, wrap_y, int(i), int(j), int(k)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._L.rtf_image_free(self.h)
+            self.h = None
 
 
 def bmp_encode(planes, gamma=-1.0):

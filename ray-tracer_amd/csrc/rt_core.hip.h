@@ -1534,8 +1534,10 @@ struct ShadeHit {           /* a hit as the shader sees it after TransformNormal
     /* Q13: a solid colour texture sets the colour (Spots: the luster) of the material this hit enters; the reference
        writes them into the shared Material, here they belong to the hit (the oracle does the same) */
     int has_color, luster_ov;       /* luster_ov < 0: the material's own */
+    int rough_ov;                   /* PlanetMapping writes ps->nRoughness = SURF_SHINY (TextureMaps.cpp:1041, 1049): the same policy; < 0: the surface's own */
     Spec color;
 };
+RT_DEV int hit_roughness(const RtDevScene &S, const ShadeHit &h) { return h.rough_ov >= 0 ? h.rough_ov : S.surfs[h.surf].roughness; }
 
 RT_DEV void perturb(ShadeHit &h, const D3 &d)      /* PerturbNormal, TextureMaps.cpp:189-198 */
 {
@@ -1720,10 +1722,155 @@ RT_DEVN void colour_texture(const RtDevScene &S, int tex, const D3 &p, ShadeHit 
     }
 }
 
+/* ---- the planet image maps: Image::Get with its wrap modes (Image.h:226-236, Image.cpp:50-89), SampleLerp / SampleLerpRGB
+   (Image.cpp:1262-1307), SampleGradient (Image.h:187-189), PlanetMapping (TextureMaps.cpp:955-1084) */
+RT_DEV int img_wrap(int i, int len, int wrap)
+{
+    if (wrap == RT_WRAP_AROUND) { i = i % len; if (i < 0) i += len; return i; }
+    if (wrap == RT_WRAP_MIRROR) { i = i % (2 * len); if (i < 0) i += 2 * len; if (i >= len) i = 2 * len - i - 1; return i; }
+    return i < 0 ? 0 : (i >= len ? len - 1 : i);
+}
+RT_DEV float img_get(const RtImageDev &im, int i, int j, int k)
+{
+    if ((unsigned)i >= (unsigned)im.w || (unsigned)j >= (unsigned)im.h) { i = img_wrap(i, im.w, im.wrap_x); j = img_wrap(j, im.h, im.wrap_y); }
+    return im.px[(size_t)i + (size_t)im.w * ((size_t)j + (size_t)im.h * (size_t)k)];
+}
+RT_DEV double img_sample_lerp(const RtImageDev &im, double x, double y, int k = 0)
+{
+    x -= 0.5; y -= 0.5;
+    const double fx = floor(x), fy = floor(y);
+    const int i1 = (int)(long long)fx, j1 = (int)(long long)fy;     /* "unsigned(floor(x))", then Get(int): the same 32 bits */
+    const double dx = x - fx, dy = y - fy;
+    double a = img_get(im, i1, j1, k), b = img_get(im, i1 + 1, j1, k), c = img_get(im, i1, j1 + 1, k), d = img_get(im, i1 + 1, j1 + 1, k);
+    a = a + dx * (b - a);
+    c = c + dx * (d - c);
+    return a + dy * (c - a);
+}
+RT_DEV void img_sample_lerp_rgb(const RtImageDev &im, double x, double y, float rgb[3])
+{
+    x -= 0.5; y -= 0.5;
+    const double fx = floor(x), fy = floor(y);
+    const int i1 = (int)(long long)fx, j1 = (int)(long long)fy;
+    const double dx = x - fx, dy = y - fy;
+    for (int k = 0; k < 3; k++) {
+        const int kc = im.ch < 3 ? 0 : k;               /* GetRGB of a grey image: the one plane three times (Image.h:275-276) */
+        float a = img_get(im, i1, j1, kc), b = img_get(im, i1 + 1, j1, kc), c = img_get(im, i1, j1 + 1, kc), d = img_get(im, i1 + 1, j1 + 1, kc);
+        /* DisplayRGB arithmetic (Image.h:67-69): float sums and differences, products with the double rounded to float */
+        a = a + (float)((double)(b - a) * dx);
+        c = c + (float)((double)(d - c) * dx);
+        rgb[k] = a + (float)((double)(c - a) * dy);
+    }
+}
+RT_DEV void img_sample_gradient(const RtImageDev &im, double x, double y, float g[2])
+{
+    g[0] = (float)(img_sample_lerp(im, x + 0.5, y) - img_sample_lerp(im, x - 0.5, y));
+    g[1] = (float)(img_sample_lerp(im, x, y + 0.5) - img_sample_lerp(im, x, y - 0.5));
+}
+#define RT_SPHEREMAPWIDTH (8 * 1024)        /* TextureMaps.cpp:943: the maps are addressed as if 8192 wide, whatever their size */
+#define RT_MAPSELECT 32.70                  /* :691 */
+RT_DEVN void planet_texture(const RtDevScene &S, int tex, const D3 &p, ShadeHit &h)
+{
+    /* colour, bump, water: the Image arguments of the wrappers (TextureMaps.cpp:1104-1242); the bump map's slot follows its colour map's */
+    int sl[3];
+    sl[0] = tex == RT_TEX_SKY ? RT_IMG_SKY : (tex <= RT_TEX_EARTH2 ? RT_IMG_EARTH : RT_IMG_MARS + 2 * (tex - RT_TEX_MARS));
+    sl[1] = tex == RT_TEX_SKY ? -1 : sl[0] + 1;
+    sl[2] = tex == RT_TEX_EARTH ? RT_IMG_EARTHWATER : -1;
+    const RtImageDev &imColor = S.images[sl[0]];
+    const D3 cvN = normalize(h.n);                  /* "cvN = Normalize(ph->cvNormal)": the normal as it stands at this call-out */
+    double x = cvN.x, y = cvN.y, z = cvN.z;
+    const double fLat = asin(z);
+    double fLong = RT_PI - atan2(p.y, p.x);
+    const double w = (double)RT_SPHEREMAPWIDTH, fKmPerPixel = 2.0 * RT_PI * 6378.137 / w;
+    if (fLong < 0.0) fLong += 2.0 * RT_PI;
+    const double fSinLat = z, fCosLat = sqrt(1.0 - z * z), r = sqrt(x * x + y * y);
+    const double fSinLong = y / r, fCosLong = x / r;
+    double fScale;
+    bool polar;
+    if (fabs(fLat * 180.0 / RT_PI) > RT_MAPSELECT) {            /* stereographic projection of the polar regions */
+        if (fabs(fLat) < 0.5 * RT_PI - 0.001) fScale = (0.5 * RT_PI - fabs(fLat)) / r;
+        else fScale = 1 / fabs(z);
+        double xp, yp;
+        if (fLat > 0.0) {
+            xp = +x / (1.0 + z) / RT_PI + 0.25;
+            yp = +y / (1.0 + z) / RT_PI + 0.25;
+            if (xp < 0.0 || xp >= 0.5) fScale = 0.0;
+        } else {
+            xp = +x / (1.0 - z) / RT_PI + 0.75;
+            yp = -y / (1.0 - z) / RT_PI + 0.25;
+            if (xp < 0.5 || xp >= 1.0) fScale = 0.0;
+        }
+        if (yp < 0.0 || yp >= 0.5) fScale = 0.0;
+        x = xp; y = yp; polar = true;
+    } else {                                                    /* Mercator projection of the equatorial region */
+        double xc = fLong / (2.0 * RT_PI);
+        if (xc >= 1.0) xc -= 1.0; else if (xc < 0.0) xc += 1.0;
+        const double yc = -log(tan(0.25 * RT_PI + 0.5 * fLat)) / (2.0 * RT_PI) + 0.75;
+        if (yc >= 0.5 && yc < 1.0) fScale = 1.0 / r; else fScale = 0.0;
+        x = xc; y = yc; polar = false;
+    }
+    double xGrad, yGrad, zGrad;
+    float g[2];
+    if (sl[2] >= 0 && img_sample_lerp(S.images[sl[2]], w * x, w * y) > 0.0) {
+        h.has_color = 1; h.color = spec_load(S.planet_spec + 5 * RT_NSPEC);        /* s_sOcean */
+        h.rough_ov = RT_SURF_SHINY;
+        img_sample_gradient(S.images[sl[2]], w * x, w * y, g);
+        xGrad = g[0] * 256.0 * fScale / fKmPerPixel;
+        yGrad = g[1] * 256.0 * fScale / fKmPerPixel;
+        zGrad = 1.0;
+    } else {
+        float rgb[3];
+        img_sample_lerp_rgb(imColor, w * x, w * y, rgb);
+        /* RGBtoSpectrum(rgb, 1), RadiometryColor.cpp:947-963 */
+        const Spec sw = spec_load(S.planet_spec), sr = spec_load(S.planet_spec + RT_NSPEC), sg = spec_load(S.planet_spec + 2 * RT_NSPEC),
+                   sb = spec_load(S.planet_spec + 3 * RT_NSPEC);
+        Spec s;
+        if (rgb[0] < rgb[1] && rgb[0] < rgb[2]) s = sw * (double)rgb[0] + sg * (double)(rgb[1] - rgb[0]) + sb * (double)(rgb[2] - rgb[0]);
+        else if (rgb[1] < rgb[0] && rgb[1] < rgb[2]) s = sw * (double)rgb[1] + sr * (double)(rgb[0] - rgb[1]) + sb * (double)(rgb[2] - rgb[1]);
+        else s = sw * (double)rgb[2] + sr * (double)(rgb[0] - rgb[2]) + sg * (double)(rgb[1] - rgb[2]);
+        const float *d65 = S.planet_spec + 4 * RT_NSPEC;
+        for (int i = 0; i < RT_NSPEC; i++) s.v[i] = d65[i] != 0.0f ? s.v[i] / d65[i] : 0.0f;
+        h.has_color = 1; h.color = s;
+        if (sl[1] >= 0) {
+            h.rough_ov = RT_SURF_SHINY;
+            img_sample_gradient(S.images[sl[1]], w * x, w * y, g);
+            xGrad = g[0] * 256.0 * fScale / fKmPerPixel;
+            yGrad = g[1] * 256.0 * fScale / fKmPerPixel;
+            zGrad = 0.0;
+        } else {
+            /* sky domes: the reference passes three uninitialised doubles to PerturbNormal here (TextureMaps.cpp:1055-1083).  Policy Q15:
+               the normal stays as it is */
+            h.luster_ov = RT_MAT_NOSHADE;
+            return;
+        }
+    }
+    double xN, yN, zN;
+    if (polar) {
+        x = +fCosLong * xGrad - -fSinLong * yGrad;
+        y = -fSinLong * xGrad + +fCosLong * yGrad;
+        z = zGrad;
+        xN = fCosLat * z - fSinLat * x;
+        yN = y;
+        zN = fSinLat * z + fCosLat * x;
+        x = fCosLong * xN - fSinLong * yN;
+        y = fSinLong * xN + fCosLong * yN;
+        z = zN;
+    } else {
+        y = xGrad;
+        x = fCosLat * zGrad - fSinLat * yGrad;
+        z = fSinLat * zGrad + fCosLat * yGrad;
+        zN = z;
+        xN = fCosLong * x - fSinLong * y;
+        yN = fSinLong * x + fCosLong * y;
+        z = zN; x = xN; y = yN;
+    }
+    perturb(h, d3(x, y, z));
+}
+
 RT_DEVN void apply_texture(const RtDevScene &S, int tex, const D3 &p, ShadeHit &h, const double *aux, float omega)        /* TextureMaps.cpp:209-369 */
 {
     float q[3], g[3];
     if (tex >= RT_TEX_VORONOI && tex <= RT_TEX_VEINS) { colour_texture(S, tex, p, h); return; }
+    if (tex >= RT_TEX_EARTH && tex <= RT_TEX_SKY) { planet_texture(S, tex, p, h); return; }
     switch (tex) {
     case RT_TEX_BUMPY: case RT_TEX_MICROFACETS: case RT_TEX_MICROFACETS2: {
         double sc = tex == RT_TEX_BUMPY ? 50.0 : (tex == RT_TEX_MICROFACETS ? 500.0 : 5000.0);
@@ -1834,7 +1981,7 @@ __device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
 template <bool LITE>
 __device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail, const double *own_minv = 0)
 {
-    h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat; h.has_color = 0; h.luster_ov = -1;
+    h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat; h.has_color = 0; h.luster_ov = -1; h.rough_ov = -1;
     if constexpr (LITE) {
         if (hr.ntex) { bail = true; return; }
         if (own_minv) { h.n = covec_mat(h.n, own_minv); return; }

@@ -197,6 +197,12 @@ typedef struct RtLightDev {
     int32_t type, no_shadow;
 } RtLightDev;
 
+/* an image of RtSceneDesc.images in device memory (PlanetMapping's maps) */
+typedef struct RtImageDev {
+    const float *px;            /* [ch][h][w], null = slot not loaded */
+    int32_t w, h, ch, wrap_x, wrap_y, pad_;
+} RtImageDev;
+
 /* constant part of a scene, one copy in device memory */
 typedef struct RtDevScene {
     const RtInstr       *prog;
@@ -249,4 +255,6 @@ typedef struct RtDevScene {
     int32_t           mesh_pre_naff, mesh_pre_chain, mesh_pre_mesh;
     int32_t           sched;                /* the scene runs the FULL kernels whose interpreter takes one class of opcodes per round (intersect_scene, SCHED): long programs, whose rays sit at different instructions */
     int32_t           mesh_pre_aff[RT_MAX_AFFINE_DEPTH];
+    const RtImageDev *images;               /* [RT_IMG__COUNT], null = the scene has no planet image-map texture */
+    const float      *planet_spec;          /* [6][RT_NSPEC]: g_sWhite, g_sRed, g_sGreen, g_sBlue, g_sD6500 (RGBtoSpectrum, RadiometryColor.cpp:947-963), s_sOcean (TextureMaps.cpp:1123) */
 } RtDevScene;

@@ -363,10 +363,21 @@ struct Flattener {
     }
     int tex_node(int tex_id, int link_node)
     {
-        static const bool ok[RT_TEX__COUNT] = { true, true, true, true, true, true, true, true, true, true, true, true, true, true, true, true,
-                                                true, true, true, true, true, true, true, true };
         if (tex_id <= 0) return -1;
-        if (tex_id >= RT_TEX__COUNT || !ok[tex_id]) { fail(RT_ERR_UNSUPPORTED, "texture call-out without a device routine yet (id " + std::to_string(tex_id) + ")"); return -1; }
+        if (tex_id >= RT_TEX__COUNT) { fail(RT_ERR_UNSUPPORTED, "texture call-out without a device routine (id " + std::to_string(tex_id) + ")"); return -1; }
+        if (tex_id >= RT_TEX_EARTH && tex_id <= RT_TEX_SKY) {       /* the planet maps: colour, bump, water (PlanetMapping's three Image arguments) */
+            static const int slots[7][3] = { { RT_IMG_EARTH, RT_IMG_EARTHBUMP, RT_IMG_EARTHWATER }, { RT_IMG_EARTH, RT_IMG_EARTHBUMP, -1 }, { RT_IMG_MARS, RT_IMG_MARSBUMP, -1 },
+                                             { RT_IMG_MOON, RT_IMG_MOONBUMP, -1 }, { RT_IMG_VENUS, RT_IMG_VENUSBUMP, -1 }, { RT_IMG_MERCURY, RT_IMG_MERCURYBUMP, -1 }, { RT_IMG_SKY, -1, -1 } };
+            for (int k = 0; k < 3; k++) {
+                const int sl = slots[tex_id - RT_TEX_EARTH][k];
+                if (sl < 0) continue;
+                if (d->n_images != RT_IMG__COUNT || !d->images) { fail(RT_ERR_INVALID, "a planet image-map texture without RtSceneDesc.images"); return -1; }
+                const RtImageMap &m = d->images[sl];
+                if (!m.pixels || m.width <= 0 || m.height <= 0 || (m.channels != 1 && m.channels != 3) || m.wrap_x < 0 || m.wrap_x > 2 || m.wrap_y < 0 || m.wrap_y > 2) {
+                    fail(RT_ERR_INVALID, "planet image-map texture " + std::to_string(tex_id) + ": image slot " + std::to_string(sl) + " is missing or malformed"); return -1;
+                }
+            }
+        }
         RtTexNode t;
         t.tex = tex_id;
         t.pa = (link_node >= 0 && link_node < (int)node_affine.size()) ? node_affine[link_node] : -1;

@@ -649,7 +649,7 @@ RT_DEV void visual_walk(const RtDevScene &S, const DRay &ray, const double *aux,
                 }
             } else
                 fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
-            int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
+            int rough = hit_roughness(S, h);            /* surf 0 (none) reads as matte: Q11 */
             if (S.has_ambient && rough != RT_SURF_POLISHED) {
                 Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
                 R = R + color * E;
@@ -869,7 +869,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                     }
                 } else
                     fresnel_real(fNE, mp.refr, mh.refr, F, fNT);
-                int rough = S.surfs[h.surf].roughness;      /* surf 0 (none) reads as matte: Q11 */
+                int rough = hit_roughness(S, h);            /* surf 0 (none) reads as matte: Q11 */
                 if (S.has_ambient && rough != RT_SURF_POLISHED) {
                     Spec E = spec_load(S.ambient) * RT_PI;      /* Lights.cpp:33-37 */
                     R = R + color * E;
@@ -1771,7 +1771,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
                 if (pm_has_color) mp_colorp = pm_color.v;
                 if (h.luster_ov >= 0) mh_luster = h.luster_ov;
             }
-            if (mp_luster != RT_MAT_TRANSPARENT || mh_luster != RT_MAT_TRANSPARENT || S.surfs[h.surf].roughness != RT_SURF_POLISHED) { blocked = true; break; }
+            if (mp_luster != RT_MAT_TRANSPARENT || mh_luster != RT_MAT_TRANSPARENT || hit_roughness(S, h) != RT_SURF_POLISHED) { blocked = true; break; }
             if (mp.prop) {
                 if constexpr (LITE) { bail = true; break; }
                 else {

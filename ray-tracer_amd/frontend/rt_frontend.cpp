@@ -591,6 +591,7 @@ TEXFN(Bumpy) TEXFN(MicroFacets) TEXFN(MicroFacets2) TEXFN(Wrinkled) TEXFN(Facete
 TEXFN(Fibers) TEXFN(Blistered) TEXFN(Hammered) TEXFN(Tectonic) TEXFN(QuasiMicroFacet)
 TEXFN(VoronoiBump) TEXFN(VoronoiAntiBump) TEXFN(VoronoiCrinkled)
 TEXFN(Voronoi) TEXFN(Agate) TEXFN(Marble) TEXFN(Clouds) TEXFN(Wood) TEXFN(Spots) TEXFN(Veins) TEXFN(SeaScape)
+TEXFN(EarthTexture) TEXFN(Earth2Texture) TEXFN(MarsTexture) TEXFN(MoonTexture) TEXFN(VenusTexture) TEXFN(MercuryTexture) TEXFN(SkyTexture)
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *) { Propagation p; p.cTransmittance = g_sEqualWhite; p.cSterisent = g_sBlack; return p; }
 /* TextureMaps.cpp:162-168 is an empty stub; here the name selects the device's Rayleigh propagator */
@@ -604,7 +605,9 @@ int rt_texture_id(TextureMap f)
         { Blistered, RT_TEX_BLISTERED }, { Hammered, RT_TEX_HAMMERED }, { Tectonic, RT_TEX_TECTONIC }, { QuasiMicroFacet, RT_TEX_QUASIMICROFACET },
         { VoronoiBump, RT_TEX_VORONOIBUMP }, { VoronoiAntiBump, RT_TEX_VORONOIANTIBUMP }, { VoronoiCrinkled, RT_TEX_VORONOICRINKLED },
         { Voronoi, RT_TEX_VORONOI }, { Agate, RT_TEX_AGATE }, { Marble, RT_TEX_MARBLE }, { Clouds, RT_TEX_CLOUDS }, { Wood, RT_TEX_WOOD },
-        { Spots, RT_TEX_SPOTS }, { Veins, RT_TEX_VEINS }, { SeaScape, RT_TEX_SEASCAPE } };
+        { Spots, RT_TEX_SPOTS }, { Veins, RT_TEX_VEINS }, { SeaScape, RT_TEX_SEASCAPE },
+        { EarthTexture, RT_TEX_EARTH }, { Earth2Texture, RT_TEX_EARTH2 }, { MarsTexture, RT_TEX_MARS }, { MoonTexture, RT_TEX_MOON },
+        { VenusTexture, RT_TEX_VENUS }, { MercuryTexture, RT_TEX_MERCURY }, { SkyTexture, RT_TEX_SKY } };
     for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) if (map[i].f == f) return map[i].id;
     return -1;
 }
@@ -873,6 +876,8 @@ void FastBlueSamplingTile::QIndex1(int prime)                  /* Sampling.cpp:5
 
 static char s_err[512];
 const char *rt_frontend_last_error() { return s_err; }
+static std::string s_asset_path;
+void SetAssetPath(const char *szDirectory) { s_asset_path = szDirectory ? szDirectory : ""; }
 
 int rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen)
 {
@@ -918,15 +923,175 @@ int rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen)
     const double aux[6] = { g_uCamera, g_vCamera, g_uLight, g_vLight, g_uMicroFacet, g_vMicroFacet };
     memcpy(d.sampler.aux_init, aux, sizeof aux);
     d.sampler.prng_x = ML_nMarsagliaX; d.sampler.prng_c = ML_nMarsagliaC;
+    /* the planet image maps the scene's textures name (LoadSkyMaps .. LoadMoonMaps, TextureMaps.cpp:1086-1234: file names, gamma and
+       wrap modes as there) */
+    static const struct { int tex; int slot[3]; } users[] = {
+        { RT_TEX_EARTH, { RT_IMG_EARTH, RT_IMG_EARTHBUMP, RT_IMG_EARTHWATER } }, { RT_TEX_EARTH2, { RT_IMG_EARTH, RT_IMG_EARTHBUMP, -1 } },
+        { RT_TEX_MARS, { RT_IMG_MARS, RT_IMG_MARSBUMP, -1 } }, { RT_TEX_MOON, { RT_IMG_MOON, RT_IMG_MOONBUMP, -1 } },
+        { RT_TEX_VENUS, { RT_IMG_VENUS, RT_IMG_VENUSBUMP, -1 } }, { RT_TEX_MERCURY, { RT_IMG_MERCURY, RT_IMG_MERCURYBUMP, -1 } },
+        { RT_TEX_SKY, { RT_IMG_SKY, -1, -1 } } };
+    static const struct { const char *file; double gamma; } files[RT_IMG__COUNT] = {
+        { "SkyColorMap.bmp", GAMMA_SRGB }, { "EarthColorMap.bmp", GAMMA_SRGB }, { "EarthBump.bmp", 1.0 }, { "EarthWater.bmp", 1.0 },
+        { "MarsColorMap.bmp", GAMMA_SRGB }, { "MarsBump.bmp", 1.0 }, { "MoonColorMap2.bmp", GAMMA_SRGB }, { "MoonBump.bmp", 1.0 },
+        { "VenusColorMap.bmp", GAMMA_SRGB }, { "VenusBump.bmp", 1.0 }, { "MercuryColorMap.bmp", GAMMA_SRGB }, { "MercuryBump.bmp", 1.0 } };
+    bool need[RT_IMG__COUNT] = { false };
+    bool any = false;
+    for (size_t i = 0; i < s.nodes.size(); i++) {
+        if (s.nodes[i].type != RT_NODE_MATERIAL && s.nodes[i].type != RT_NODE_SURFACE) continue;
+        for (size_t u = 0; u < sizeof users / sizeof users[0]; u++)
+            if (s.nodes[i].i1 == users[u].tex)
+                for (int k = 0; k < 3; k++) if (users[u].slot[k] >= 0) { need[users[u].slot[k]] = true; any = true; }
+    }
+    for (size_t i = 0; i < out.image_store.size(); i++) delete out.image_store[i];
+    out.image_store.clear(); out.images.clear();
+    if (any) {
+        const char *env = getenv("RT_AMD_ASSETS");
+        const std::string dir = !s_asset_path.empty() ? s_asset_path : std::string(env ? env : "");
+        if (dir.empty()) { snprintf(err, errlen, "the scene uses the planet image-map textures (TextureMaps.cpp:955-1243), whose BMP files the reference does not ship: give their directory with SetAssetPath() or RT_AMD_ASSETS"); return -1; }
+        RtImageMap none;
+        memset(&none, 0, sizeof none);
+        out.images.assign(RT_IMG__COUNT, none);
+        for (int k = 0; k < RT_IMG__COUNT; k++) {
+            if (!need[k]) continue;
+            Image *im = new Image;
+            out.image_store.push_back(im);
+            const std::string path = dir + "/" + files[k].file;
+            if (!im->ReadBMP(path.c_str(), files[k].gamma)) { snprintf(err, errlen, "cannot read %s (Image::ReadBMP, Image.cpp:95-288)", path.c_str()); return -1; }
+            im->m_bWrapX = WRAP_AROUND; im->m_bWrapY = WRAP_MIRROR;
+            RtImageMap &m = out.images[k];
+            m.width = im->m_nWidth; m.height = im->m_nHeight; m.channels = im->m_nChannels; m.wrap_x = im->m_bWrapX; m.wrap_y = im->m_bWrapY; m.pixels = im->m_pfImage;
+        }
+        d.n_images = RT_IMG__COUNT; d.images = &out.images[0];
+    }
     return 0;
 }
 
-int Image::NewImage(int w, int h, int channels)
+int Image::NewImage(int w, int h, int channels, int bWrapX, int bWrapY)
 {
     int64_t n = (int64_t)w * h * channels, old = (int64_t)m_nWidth * m_nHeight * m_nChannels;
     if (!m_pfImage || n != old) { delete[] m_pfImage; m_pfImage = new float[n]; }
     m_nWidth = w; m_nHeight = h; m_nChannels = channels;
+    m_bWrapX = bWrapX; m_bWrapY = bWrapY;
     return m_pfImage != 0;
+}
+
+static inline int ML_Modulus(int n, int m) { n = n % m; if (n < 0) n += m; return n; }      /* Image.cpp:50-57 */
+static inline int ML_Wrap(int &i, int nLength, int nWrap)                                   /* Image.cpp:59-83 */
+{
+    int bDraw = 1;
+    if (nWrap == WRAP_AROUND) i = ML_Modulus(i, nLength);
+    else if (nWrap == WRAP_MIRROR) { i = ML_Modulus(i, 2 * nLength); if (i >= nLength) i = 2 * nLength - i - 1; }
+    else { bDraw = 0; if (i < 0) i = 0; else if (i >= nLength) i = nLength - 1; else bDraw = 1; }
+    return bDraw;
+}
+int Image::Wrap(int &iCol, int &jRow) const { return ML_Wrap(iCol, m_nWidth, m_bWrapX) & ML_Wrap(jRow, m_nHeight, m_bWrapY); }
+
+void Image::SetGamma(double fGamma)             /* Image.cpp:497-517, the decode half */
+{
+    if (fGamma == GAMMA_SRGB) {
+        for (int n = 0; n < 256; n++) {
+            double f = double(n) * (1.0 / 255.0);
+            if (f <= 0.03928) f = f / 12.92;
+            else f = float(pow((f + 0.055) / 1.055, 2.4));
+            m_rgfGammaT[n] = float(f);
+        }
+    } else
+        for (int n = 0; n < 256; n++) m_rgfGammaT[n] = float(pow(double(n) * (1.0 / 255.0), fGamma));
+}
+
+int Image::ReadBMP(const char *szFileName, double fGamma)
+{
+    FILE *pf = fopen(szFileName, "rb");
+    if (!pf) return 0;
+    std::vector<unsigned char> line;
+    unsigned char head[54], pal[256][4];
+    unsigned mask[3] = { 0, 0, 0 };     /* red, green, blue */
+    int shift[3] = { 0, 0, 0 };
+    int ok = 0;
+    do {
+        if (fread(head, 1, 54, pf) != 54 || head[0] != 'B' || head[1] != 'M') break;
+        #define U32(o) ((unsigned)head[o] | ((unsigned)head[(o) + 1] << 8) | ((unsigned)head[(o) + 2] << 16) | ((unsigned)head[(o) + 3] << 24))
+        #define U16(o) ((unsigned)head[o] | ((unsigned)head[(o) + 1] << 8))
+        const unsigned width = U32(18), height = U32(22), bits = U16(28), compression = U32(30), clr_used = U32(46);
+        #undef U32
+        #undef U16
+        if (width == 0 || height == 0 || width > (1u << 20) || height > (1u << 20)) break;
+        if (bits != 1 && bits != 4 && bits != 8 && bits != 16 && bits != 24 && bits != 32) break;
+        if (compression == 0) {
+            if (bits == 16) { mask[0] = 0x7C00; mask[1] = 0x03E0; mask[2] = 0x001F; }
+            else if (bits == 32) { mask[0] = 0x00FF0000; mask[1] = 0x0000FF00; mask[2] = 0x000000FF; }
+        } else if (compression == 3) {
+            unsigned char m[12];
+            if (fread(m, 1, 12, pf) != 12) break;
+            for (int k = 0; k < 3; k++) mask[k] = (unsigned)m[4 * k] | ((unsigned)m[4 * k + 1] << 8) | ((unsigned)m[4 * k + 2] << 16) | ((unsigned)m[4 * k + 3] << 24);
+        } else
+            break;                      /* only RGB and BITFIELD compression */
+        if (bits == 16 || bits == 32) {
+            bool bad = false;
+            for (int k = 0; k < 3; k++) {
+                for (shift[k] = 0; shift[k] < 32; shift[k]++) if (mask[k] & (1u << shift[k])) break;
+                if (shift[k] == 32) bad = true;         /* (the reference would divide by zero / shift by 32) */
+            }
+            if (bad) break;
+        }
+        int nColors;
+        if (clr_used) nColors = (int)clr_used;
+        else if (bits == 1) nColors = 2;
+        else if (bits == 4) nColors = 16;
+        else if (bits == 8) nColors = 256;
+        else nColors = 0;
+        if (nColors < 0 || nColors > 256) break;
+        if (nColors && fread(pal, 1, (size_t)4 * nColors, pf) != (size_t)4 * nColors) break;
+        int nChannels;
+        if (nColors == 0) nChannels = bits >= 16 ? 3 : 1;
+        else {
+            nChannels = 1 + 2 * (bits >= 16);
+            for (int i = 0; i < nColors; i++) if (pal[i][2] != pal[i][1] || pal[i][2] != pal[i][0]) { nChannels = 3; break; }
+        }
+        const size_t nLineSize = 4 * (((size_t)width * bits + 31) >> 5);
+        line.resize(nLineSize);
+        if (!NewImage((int)width, (int)height, nChannels)) break;
+        SetGamma(fGamma);
+        bool short_read = false;
+        for (int j = m_nHeight - 1; j >= 0 && !short_read; --j) {
+            if (fread(&line[0], 1, nLineSize, pf) != nLineSize) { short_read = true; break; }
+            for (int i = 0; i < m_nWidth; i++) {
+                int iRed = 0, iGrn = 0, iBlu = 0;
+                unsigned nPixel;
+                switch (bits) {
+                case 1:  iRed = (line[i >> 3] >> (7 - (i & 7))) & 1; break;
+                case 4:  iRed = (line[i >> 1] >> (4 - 4 * (i & 1))) & 15; break;
+                case 8:  iRed = line[i]; break;
+                case 16:
+                    nPixel = line[2 * i] | (line[2 * i + 1] << 8);
+                    iBlu = (int)((nPixel & mask[2]) >> shift[2]); iGrn = (int)((nPixel & mask[1]) >> shift[1]); iRed = (int)((nPixel & mask[0]) >> shift[0]);
+                    iBlu = (255 * iBlu) / (int)(mask[2] >> shift[2]); iGrn = (255 * iGrn) / (int)(mask[1] >> shift[1]); iRed = (255 * iRed) / (int)(mask[0] >> shift[0]);
+                    break;
+                case 24: iRed = line[3 * i + 2]; iGrn = line[3 * i + 1]; iBlu = line[3 * i]; break;
+                default:
+                    nPixel = (unsigned)line[4 * i] | ((unsigned)line[4 * i + 1] << 8) | ((unsigned)line[4 * i + 2] << 16) | ((unsigned)line[4 * i + 3] << 24);
+                    iBlu = (int)((nPixel & mask[2]) >> shift[2]); iGrn = (int)((nPixel & mask[1]) >> shift[1]); iRed = (int)((nPixel & mask[0]) >> shift[0]);
+                    break;
+                }
+                if (bits <= 8) {
+                    if (iRed >= nColors) { iRed = iGrn = iBlu = 0; }        /* (an index past the colour map: the reference reads its uninitialised tail) */
+                    else { iBlu = pal[iRed][0]; iGrn = pal[iRed][1]; iRed = pal[iRed][2]; }
+                }
+                #define DECODE(n) ((n) < 0 ? 0.0f : ((n) > 255 ? 1.0f : m_rgfGammaT[n]))    /* GammaDecode, Image.h:197-205 */
+                m_pfImage[i + m_nWidth * (int64_t)j] = DECODE(iRed);
+                if (m_nChannels >= 3) {
+                    m_pfImage[i + m_nWidth * (int64_t)(j + m_nHeight)] = DECODE(iGrn);
+                    m_pfImage[i + m_nWidth * (int64_t)(j + 2 * m_nHeight)] = DECODE(iBlu);
+                }
+                #undef DECODE
+            }
+        }
+        if (short_read) break;
+        ok = 1;
+    } while (0);
+    fclose(pf);
+    if (!ok) { delete[] m_pfImage; m_pfImage = 0; m_nWidth = m_nHeight = m_nChannels = 0; }
+    return ok;
 }
 
 int Image::WriteBMP(const char *szFileName, double fGamma)

@@ -172,13 +172,29 @@ void BuildQuasiIndex(int rgn[], int prime, int n);          /* Patterns.h */
 void FibonacciSphere(double rgf[], int i, int n);
 
 /* --------------------------------------------------------------------------- Image (Image.h) ---- */
+#define WRAP_CLAMP   0                          /* Image.h:17-19 */
+#define WRAP_AROUND  1
+#define WRAP_MIRROR  2
+#define GAMMA_SRGB   -1.0                       /* Image.h:21 */
 struct Image {
     float *m_pfImage;
     int    m_nHeight, m_nWidth, m_nChannels;
-    Image() : m_pfImage(0), m_nHeight(0), m_nWidth(0), m_nChannels(0) {}
+    int    m_bWrapX, m_bWrapY;
+    float  m_rgfGammaT[256];                    /* decode table of the last SetGamma (Image.cpp:497-517) */
+    Image() : m_pfImage(0), m_nHeight(0), m_nWidth(0), m_nChannels(0), m_bWrapX(WRAP_MIRROR), m_bWrapY(WRAP_MIRROR) {}
     ~Image() { delete[] m_pfImage; }
-    int NewImage(int w, int h, int channels = 1);
-    float Get(int i, int j, int k = 0) const { return m_pfImage[i + m_nWidth * (int64_t)(j + m_nHeight * k)]; }
+    int NewImage(int w, int h, int channels = 1, int bWrapX = WRAP_MIRROR, int bWrapY = WRAP_MIRROR);
+    /* Image::ReadBMP (Image.cpp:95-288): version-3 BMP of 1, 4, 8, 16, 24 or 32 bits per pixel, BI_RGB or BI_BITFIELDS, to linear
+       floats through the gamma table.  Returns 1, or 0 on error (and frees the image) like the reference. */
+    int ReadBMP(const char *szFileName, double fGamma = GAMMA_SRGB);
+    void SetGamma(double fGamma);
+    int Wrap(int &iCol, int &jRow) const;       /* Image.cpp:50-89 */
+    float Get(int iCol, int jRow, int k = 0) const      /* Image.h:226-236 */
+    {
+        int i = iCol, j = jRow;
+        if ((unsigned)i >= (unsigned)m_nWidth || (unsigned)j >= (unsigned)m_nHeight) Wrap(i, j);
+        return m_pfImage[i + m_nWidth * (int64_t)(j + m_nHeight * k)];
+    }
     DisplayRGB GetRGB(int i, int j) const { return DisplayRGB(Get(i, j, 0), Get(i, j, 1), Get(i, j, 2)); }
     /* Image::WriteBMP (Image.cpp:416-474), 3-channel images: clamp to gamut + gamma-encode on the GPU (rt_bmp_encode),
        then the file is written here.  Returns 1, or 0 on error like the reference. */
@@ -368,6 +384,17 @@ void Wood(const Point3 &, Hit *, RayTracer *);
 void Spots(const Point3 &, Hit *, RayTracer *);
 void Veins(const Point3 &, Hit *, RayTracer *);
 void SeaScape(const Point3 &, Hit *, RayTracer *);
+/* the planet image maps (TextureMaps.cpp:1098-1243).  The reference reads "EarthColorMap.bmp", "EarthBump.bmp", ... from the working
+   directory at the first hit and does not ship them; here rt_flatten reads the files a scene's textures name from the asset
+   directory -- SetAssetPath(), or the environment's RT_AMD_ASSETS -- and fails when one is missing. */
+void EarthTexture(const Point3 &, Hit *, RayTracer *);
+void Earth2Texture(const Point3 &, Hit *, RayTracer *);
+void MarsTexture(const Point3 &, Hit *, RayTracer *);
+void MoonTexture(const Point3 &, Hit *, RayTracer *);
+void VenusTexture(const Point3 &, Hit *, RayTracer *);
+void MercuryTexture(const Point3 &, Hit *, RayTracer *);
+void SkyTexture(const Point3 &, Hit *, RayTracer *);
+void SetAssetPath(const char *szDirectory);     /* null or "": back to RT_AMD_ASSETS */
 Propagation ColoredGlass(const Point3 &, const Point3 &, Material *, RayTracer *);
 Propagation Foggy(const Point3 &, const Point3 &, Material *, RayTracer *);
 Propagation Atmosphere(const Point3 &, const Point3 &, Material *, RayTracer *);
@@ -613,7 +640,14 @@ struct RtSerializer {
 struct RtSceneBlob {                            /* owns every array an RtSceneDesc points to */
     RtSerializer ser;
     std::vector<int32_t> qi2, qi3;
+    std::vector<RtImageMap> images;             /* RT_IMG__COUNT entries when a planet texture is used */
+    std::vector<Image *> image_store;
     RtSceneDesc desc;
+    RtSceneBlob() {}
+    ~RtSceneBlob() { for (size_t i = 0; i < image_store.size(); i++) delete image_store[i]; }
+private:
+    RtSceneBlob(const RtSceneBlob &);
+    RtSceneBlob &operator=(const RtSceneBlob &);
 };
 int  rt_flatten(const RayTracer &rt, RtSceneBlob &out, char *err, int errlen);
 const char *rt_frontend_last_error();

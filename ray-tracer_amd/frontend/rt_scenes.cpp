@@ -396,6 +396,7 @@ struct Parser {
             else if (w == "add") { Spectrum a = spectrum(), b = spectrum(); s = a + b; }
             else if (w == "blackbody") s = BlackBody(num());
             else if (w == "rgb") { double r = num(), g = num(), b = num(); s = RGBtoSpectrum(DisplayRGB(r, g, b)); }
+            else if (w == "rgb6500") { double r = num(), g = num(), b = num(); s = RGBtoSpectrum(DisplayRGB(r, g, b), 1); }
             else if (w == "gray") s = RGBtoSpectrum(num());
             else fail("unknown spectrum form " + w);
             close();
@@ -429,7 +430,9 @@ struct Parser {
             { "tectonic", Tectonic }, { "quasimicrofacet", QuasiMicroFacet }, { "voronoibump", VoronoiBump },
             { "voronoiantibump", VoronoiAntiBump }, { "voronoicrinkled", VoronoiCrinkled },
             { "voronoi", Voronoi }, { "agate", Agate }, { "marble", Marble }, { "clouds", Clouds }, { "wood", Wood }, { "spots", Spots },
-            { "veins", Veins }, { "seascape", SeaScape } };
+            { "veins", Veins }, { "seascape", SeaScape },
+            { "earth", EarthTexture }, { "earth2", Earth2Texture }, { "mars", MarsTexture }, { "moon", MoonTexture }, { "venus", VenusTexture },
+            { "mercury", MercuryTexture }, { "sky", SkyTexture } };
         for (size_t i = 0; i < sizeof t / sizeof t[0]; i++) if (w == t[i].n) return t[i].f;
         fail("unknown texture " + w);
         return 0;
@@ -714,3 +717,19 @@ extern "C" int rtf_write_video(const char *path, const float *frames, int nframe
     vd.Close();
     return n;
 }
+
+/* the directory of the planet image maps (SetAssetPath) */
+extern "C" void rtf_set_asset_path(const char *dir) { SetAssetPath(dir); }
+
+/* Image::ReadBMP + Image::Get through the front end, for the tests: read a file, report width, height, channels, copy the planes out,
+   and read single pixels through the wrap modes */
+extern "C" void *rtf_image_read_bmp(const char *path, double gamma, int *whc3)
+{
+    Image *im = new Image;
+    if (!im->ReadBMP(path, gamma)) { snprintf(s_scene_err, sizeof s_scene_err, "ReadBMP failed: %s", path); delete im; return 0; }
+    whc3[0] = im->m_nWidth; whc3[1] = im->m_nHeight; whc3[2] = im->m_nChannels;
+    return im;
+}
+extern "C" void rtf_image_planes(void *h, float *out) { Image *im = (Image *)h; memcpy(out, im->m_pfImage, sizeof(float) * (size_t)im->m_nWidth * im->m_nHeight * im->m_nChannels); }
+extern "C" float rtf_image_get(void *h, int wrap_x, int wrap_y, int i, int j, int k) { Image *im = (Image *)h; im->m_bWrapX = wrap_x; im->m_bWrapY = wrap_y; return im->Get(i, j, k); }
+extern "C" void rtf_image_free(void *h) { delete (Image *)h; }

@@ -5,8 +5,9 @@
  * cheapest way to meet every limit of the flattener (nested regions and boxes, nested affines, hit-list depth).
  *
  * Names (argument after '@', default in brackets):
- *   Model2..Model9, ModelA..ModelV [@angle 30]   TestScene.cpp:79-1145  (MakeModel2 ... MakeModelV; L4, L5 and U need the
- *                                                planet image maps, which the reference does not ship: refused)
+ *   Model2..Model9, ModelA..ModelV [@angle 30]   TestScene.cpp:79-1145  (MakeModel2 ... MakeModelV; L4, L5 and U use the
+ *                                                planet image maps, which the reference does not ship: they need an
+ *                                                asset directory -- SetAssetPath() / RT_AMD_ASSETS -- and fail without)
  *   Fib[@N 200]          MakeModelFib (:1147-1174): Fibonacci polyhedron with two SolidText labels
  *   Ruby[@angle 20]      MakeModelRuby (:1194-1224): bumpy metal dodecahedron cages around hollow gem stones
  *   Letters              MakeModelLetters (:1226-1235): SolidText("Hello World!")
@@ -421,6 +422,26 @@ Solid *ModelQ(double a)         /* :1026-1066 six shapes of the library */
 
 Solid *ModelR(double a) { return turn(0.25 * D_PI, 0.0, 0.0, PseudoHelix(0.2, 0.5, rad(a))); }             /* :1068-1081 (the code before its first return) */
 Solid *ModelS(double r) { return turn(0.0, 0.5 * D_PI, 0.0, Plastic(Knoboid(r, 1.0))); }                     /* :1083-1093 */
+
+Solid *ModelL4(double a)        /* :815-831 the Earth on a sphere.  Camera z = 5.0 */
+{
+    return at(0.0, 0.0, 0.0, turn(rad(90.0), rad(a), 0.0,
+           tex(0.9, pale(g_sBlue, g_sWhite), MAT_PLASTIC, EarthTexture, surf(SURF_SHINY, 0, turn(0.0, 0.0, 0.0, new Sphere)))));
+}
+Solid *ModelL5(double a)        /* :833-849 the Earth on a torus.  Camera z = 5.0 */
+{
+    const double x = rad(-90.0);
+    return at(0.0, 0.0, 0.0, turn(x, rad(a), 0.0,
+           tex(0.9, pale(g_sBlue, g_sWhite), MAT_PLASTIC, EarthTexture, surf(SURF_SHINY, 0, turn(-x, 0.0, 0.0, new Torus(0.3))))));
+}
+Solid *ModelU(double a)         /* :1111-1129 the Earth (no water mask) inside a textured sky dome */
+{
+    Solid *ps = new Rotate(0.5 * D_PI, rad(a), 0.0, tex(0.9, g_sEqualWhite, MAT_PLASTIC, Earth2Texture, surf(SURF_SMOOTH, 0, new Sphere)), "xyz");
+    Solid *sky = size(100.0, tex(0.9, g_sEarthSky * 2.0, MAT_NOSHADE, SkyTexture, new HollowSphere));
+    sky = turn(rad(90.0), 0.0, 0.0, sky);
+    sky = turn(0.0, 0.0, rad(33.0), sky);
+    return join(ps, sky);
+}
 
 Solid *ModelT(double)           /* :1095-1109 a ring of 36 spheres around the camera */
 {
@@ -867,15 +888,12 @@ int rt_build_conformance_scene(const char *spec, RayTracer &rt, std::string *err
     const bool has = !arg.empty();
     const double a = has ? atof(arg.c_str()) : 30.0;
 
-    if (name == "ModelL4" || name == "ModelL5" || name == "ModelU") {
-        if (err) *err = name + " uses the planet image-map textures (TextureMaps.cpp:703-1250), whose BMP assets the reference does not ship";
-        return -1;
-    }
     static const struct { const char *n; Solid *(*f)(double); double cam_z; } models[] = {
         { "Model2", Model2, 8.0 }, { "Model3", Model3, 9.0 }, { "Model4", Model4, 8.0 }, { "Model5", Model5, 9.0 }, { "Model7", Model7, 8.0 },
         { "Model8", Model8, 9.0 }, { "Model9", Model9, 8.0 }, { "ModelA", ModelA, 8.0 }, { "ModelB", ModelB, 8.0 }, { "ModelC", ModelC, 8.0 },
         { "ModelE", ModelE, 8.0 }, { "ModelF", ModelF, 8.0 }, { "ModelG2", ModelG2, 8.0 }, { "ModelH", ModelH, 8.0 }, { "ModelI", ModelI, 8.0 },
-        { "ModelJ", ModelJ, 9.0 }, { "ModelL", ModelL, 9.0 }, { "ModelL2", ModelL2, 9.0 }, { "ModelL3", ModelL3, 9.0 }, { "ModelM", ModelM, 8.0 },
+        { "ModelJ", ModelJ, 9.0 }, { "ModelL", ModelL, 9.0 }, { "ModelL2", ModelL2, 9.0 }, { "ModelL3", ModelL3, 9.0 }, { "ModelL4", ModelL4, 5.0 }, { "ModelL5", ModelL5, 5.0 },
+        { "ModelU", ModelU, 5.0 }, { "ModelM", ModelM, 8.0 },
         { "ModelN", ModelN, 8.0 }, { "ModelO", ModelO, 8.0 }, { "ModelP", ModelP, 8.0 }, { "ModelQ", ModelQ, 8.0 }, { "ModelR", ModelR, 8.0 },
         { "ModelT", ModelT, 5.0 }, { "ModelV", ModelV, 8.0 }, { "Letters", ModelLetters, 8.0 },
         { "SetOperations", ModelSetOperations, 8.0 }, { "HyperTest", ModelHyperTest, 8.0 }, { "TestTop", ModelTestTop, 12.0 } };

@@ -16,18 +16,12 @@ EXACT = ["Model4", "Model4@90", "Model5", "Model7", "ModelB", "ModelE", "ModelI"
          "SetOperations", "HyperTest", "Lorenz@50", "TestTop", "Fib@60", "Letters", "Unicyclist@0.3", "Megacycles@0.25", "ModelJ", "ModelL", "ModelL3"]
 LIBM = ["Model2", "Model3", "Model6", "Model8", "Model9", "ModelA", "ModelC", "ModelD", "ModelF", "ModelG", "ModelG2", "ModelH", "ModelK",
         "ModelL2", "ModelM", "ModelP", "ModelQ", "ModelR@400", "Ruby", "Venera@40", "VeneraVenus"]
-REFUSED = ["ModelL4", "ModelL5", "ModelU"]
+# ModelL4, ModelL5 and ModelU (the planet image maps) run on synthetic assets in tests/test_image_maps.py
 
 
 def _rel_rmse(a, b):
     a = a.astype(np.float64); b = b.astype(np.float64)
     return float(np.sqrt(((a - b) ** 2).mean()) / max(1e-30, np.sqrt((b ** 2).mean())))
-
-
-@pytest.mark.parametrize("name", REFUSED)
-def test_scenes_that_need_absent_assets_are_refused(rt, name):
-    with pytest.raises(rt.RtError, match="image-map"):
-        rt.FrontScene(name, "", optimize=True)
 
 
 def test_unknown_scene_name_is_an_error(rt):
