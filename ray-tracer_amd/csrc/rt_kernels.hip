@@ -177,6 +177,16 @@ __global__ void k_probe_camera(const RtDevScene Sv, int n, const double *v2, con
 }
 
 /* root ray k of a chunk: sample first + k of the grid, or user ray k (probes) */
+/* sample first + k of the grid -> its tile and its index in the tile.  `first` is the same for a whole launch: its quotient and
+   remainder are scalar work, and what is left per sample is a 32-bit division by a constant (the 64-bit one is a sequence of some
+   thirty instructions, and the generator and the fast kernels ran it two or three times per sample) */
+RT_DEV uint32_t tile_of(const int64_t first, const int k, int &i)
+{
+    const int64_t ft = first / RT_BLUE_N;
+    const uint32_t u = (uint32_t)(first - ft * RT_BLUE_N) + (uint32_t)k, q = u / (uint32_t)RT_BLUE_N;
+    i = (int)(u - q * (uint32_t)RT_BLUE_N);
+    return (uint32_t)ft + q;
+}
 RT_DEV void root_ray(const RtDevScene &S, const RtSampleGrid &g, int64_t first, int k, const double *rays_org, const double *rays_dir, const double *rays_aux,
                      DRay &r, double *aux)
 {
@@ -206,9 +216,8 @@ RT_DEV DRay root_ray_for_cull(const RtDevScene &S, const RtSampleGrid &g, int64_
         sample_at(S, g, first + k, pos, v, aux);
         return camera_emit(S.cam, v[0], v[1], aux[0], aux[1]);
     }
-    const int64_t s = first + k;
-    const uint32_t tile = (uint32_t)(s / RT_BLUE_N);
-    const int i = (int)(s - (int64_t)tile * RT_BLUE_N);
+    int i;
+    const uint32_t tile = tile_of(first, k, i);
     const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
     const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
     const double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + (double)tx * (double)RT_BLUE_NSQRT;
@@ -408,7 +417,8 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         if (k < n) {
             k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
-            const int64_t tile = (first + k) / RT_BLUE_N;
+            int ti_;
+            const uint32_t tile = tile_of(first, k, ti_);
             const int tm = (g.tile_mask && !rays_org) ? (int)g.tile_mask[tile] : 255;
             const bool masked = tm == 0;
             if (!masked) {
@@ -472,7 +482,8 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
         root_ray(S, g, first, k, rays_org, rays_dir, rays_aux, r, aux);
         int hint = 0;
         if (g.tile_mask && g.tile_cand && !rays_org) {
-            const int64_t tile = (first + k) / RT_BLUE_N;
+            int ti_;
+            const uint32_t tile = tile_of(first, k, ti_);
             if (g.tile_mask[tile] == 1) { const int c = g.tile_cand[(size_t)tile * RT_TILE_CAND]; if (c < 2047) hint = c + 1; }
         }
         root_frame(S, P, block_base[0] + wave_base[0][it][wave] + (int)((prefix >> (7 * it)) & 127u), k, r, aux, hint);
@@ -1268,10 +1279,9 @@ RT_HD size_t fast_shade_lds_bytes(int n_mats, int n_surfs, int n_lights)
 }
 /* FastBlueSamplingTile::Render, Sampling.cpp:498-517 + CastFunction, RayTracer2020.cpp:20-31 for sample sidx of the grid: as sample_at / root_ray
    (no aperture camera on the fast path: the lens pair is not needed) */
-RT_DEV DRay fast_ray(const RtDevScene &S, const RtSampleGrid &g, const int64_t sidx, uint32_t &tile, int &i)
+RT_DEV DRay fast_ray(const RtDevScene &S, const RtSampleGrid &g, const int64_t first, const int k, uint32_t &tile, int &i)
 {
-    tile = (uint32_t)(sidx / RT_BLUE_N);
-    i = (int)(sidx - (int64_t)tile * RT_BLUE_N);
+    tile = tile_of(first, k, i);
     const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
     const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
     const double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
@@ -1332,7 +1342,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTA_THREADS, 1) 
         const int code = nt_load(&P.fast_q[(size_t)P.ncap + e]);
         uint32_t tile;
         int isamp;
-        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        const DRay ray = fast_ray(S, g, first, k, tile, isamp);
         RegEmit H;
         H.L = 0; H.minv_own = 0;
         /* (one loop for both cases -- one copy of the chain code, 3400 instructions instead of 4800 -- was measured and is slower: 2.53
@@ -1406,7 +1416,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTA_THREADS, 1) 
             double aux[6];
             uint32_t tile;
             int isamp;
-            const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+            const DRay ray = fast_ray(S, g, first, k, tile, isamp);
             fast_aux(S, isamp, aux);
             root_frame(S, P, f, k, ray, aux, 0);
         }
@@ -1478,7 +1488,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTB_THREADS, 1) 
         uint32_t tile;
         int isamp;
         double aux[6];
-        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        const DRay ray = fast_ray(S, g, first, k, tile, isamp);
         fast_aux(S, isamp, aux);
         Walk B;
         RegSink K;
@@ -1505,7 +1515,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTB_THREADS, 1) 
         uint32_t tile;
         int isamp;
         double aux[6];
-        const DRay ray = fast_ray(S, g, first + k, tile, isamp);
+        const DRay ray = fast_ray(S, g, first, k, tile, isamp);
         fast_aux(S, isamp, aux);
         aux_store(S, P, k, aux);
         P.f_parent[f] = -1;
@@ -2530,7 +2540,11 @@ RT_DEV void splat_pixel_lds(const RtSampleGrid &g, const SplatRowLds &L, const f
             const int so = ly == L.cy1 ? RT_FS_OFFS : 0;       /* which staged cell row: ly is the row itself or cy1 by construction */
             const int e0 = L.off[so + lx + 1], e1 = L.off[so + lx + 2];
             const int tile = tx * g.tiles_y_local + (ty - g.tile_y0);
+#ifdef RT_RECON_DEBUG
+            const int64_t sbase = (g.pad_ & 4) ? 0 : (int64_t)tile * RT_BLUE_N;      /* (debug: every lane reads the first tile's colours) */
+#else
             const int64_t sbase = (int64_t)tile * RT_BLUE_N;
+#endif
             const bool black = g.tile_mask && g.mask_skips_rgb && g.tile_mask[tile] == 0;
             for (int e = e0; e < e1; e++) {
                 const RtSplatEntry en = L.ent[e];
