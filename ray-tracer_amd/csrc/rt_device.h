@@ -255,6 +255,7 @@ typedef struct RtDevScene {
     int32_t           mesh_pre_naff, mesh_pre_chain, mesh_pre_mesh;
     int32_t           sched;                /* the scene runs the FULL kernels whose interpreter takes one class of opcodes per round (intersect_scene, SCHED): long programs, whose rays sit at different instructions */
     int32_t           mesh_pre_aff[RT_MAX_AFFINE_DEPTH];
+    const float      *cull32;               /* parallel to region_child_boxes: lo[3], hi[3] in single precision, grown for float arithmetic (k_generate_cull); null = off */
     const RtImageDev *images;               /* [RT_IMG__COUNT], null = the scene has no planet image-map texture */
     const float      *planet_spec;          /* [6][RT_NSPEC]: g_sWhite, g_sRed, g_sGreen, g_sBlue, g_sD6500 (RGBtoSpectrum, RadiometryColor.cpp:947-963), s_sOcean (TextureMaps.cpp:1123) */
 } RtDevScene;

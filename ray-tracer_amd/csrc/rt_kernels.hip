@@ -422,6 +422,53 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
             const int tm = (g.tile_mask && !rays_org) ? (int)g.tile_mask[tile] : 255;
             const bool masked = tm == 0;
             if (!masked) {
+                if (tm != 255 && fast_on && S.cull32 && S.cam.type <= RT_CAM_STEREOGRAPHIC) {
+                    /* The tile's list in single precision (option cull_f32).  This test only decides which of the listed boxes a sample is
+                       tried against: a box kept in error costs a chain test that misses, a box dropped in error would lose a hit -- so
+                       the boxes of S.cull32 are the culling boxes grown by 1e-4 of the scene's scale (camera distance + box
+                       coordinates), some thirty times what this arithmetic can be off by: the direction is good to ~1e-6 relative
+                       (a dozen float operations on numbers of order one), so a point at distance L along the ray is displaced by
+                       L * 1e-6, and the slab arithmetic adds a few float roundings of numbers up to the scene's scale.  A direction
+                       component too small to invert asks whether the origin lies between the planes, as cull_ray does.  The survivors'
+                       rays are computed exactly by the kernels that take them. */
+                    const uint32_t txu = tile / (uint32_t)g.tiles_y_local;
+                    const int tx = (int)txu, ty = (int)(tile - txu * (uint32_t)g.tiles_y_local) + g.tile_y0;
+                    const float vx = (float)S.blue[2 * ti_] * (float)RT_BLUE_NSQRT + (float)(tx * RT_BLUE_NSQRT);
+                    const float vy = (float)S.blue[2 * ti_ + 1] * (float)RT_BLUE_NSQRT + (float)(ty * RT_BLUE_NSQRT);
+                    const float v0 = (vx + (float)g.adjust_x) * (float)g.inv_size, v1 = (vy + (float)g.adjust_y) * (float)g.inv_size;
+                    const float kf = 35.0f / (float)S.cam.focal;
+                    const float x = (v0 - 0.5f) * kf, y = (v1 - 0.5f) * kf;
+                    float d[3];
+                    if (S.cam.type == RT_CAM_PERSPECTIVE) { d[0] = x; d[1] = y; d[2] = -1.0f; }
+                    else { const float id = __builtin_amdgcn_rcpf(x * x + y * y + 4.0f); d[0] = 4.0f * x * id; d[1] = 4.0f * y * id; d[2] = 1.0f - 8.0f * id; }
+                    const float o[3] = { (float)S.cam.org[0], (float)S.cam.org[1], (float)S.cam.org[2] };
+                    float inv[3], noi[3];
+                    bool par[3];
+                    for (int a = 0; a < 3; a++) {
+                        par[a] = !(fabsf(d[a]) > 1.0e-30f);
+                        inv[a] = par[a] ? 0.0f : __builtin_amdgcn_rcpf(d[a]);
+                        noi[a] = -(o[a] * inv[a]);
+                    }
+                    const float *cb = S.cull32 + (size_t)6 * S.regions[S.root_cull_arg].child_pc0;
+                    const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
+                    unsigned m = 0;
+                    bool elig = true;
+                    int c1 = 0;
+                    for (int q = 0; q < tm; q++) {
+                        const float *bx = cb + 6 * (size_t)tl[q];
+                        float t0 = 0.0f, t1 = 3.0e38f;
+                        bool in = true;
+                        for (int a = 0; a < 3; a++) {
+                            if (!par[a]) {
+                                const float ta = __builtin_fmaf(bx[a], inv[a], noi[a]), tb = __builtin_fmaf(bx[3 + a], inv[a], noi[a]);
+                                t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                            } else in = in && !(o[a] < bx[a] || o[a] > bx[3 + a]);
+                        }
+                        if (in && t0 - t1 <= (fabsf(t0) + fabsf(t1)) * 4.0e-6f) { m |= 1u << q; c1 = S.root_fast[tl[q]]; elig = elig && c1 >= 0; }
+                    }
+                    keep = m != 0;
+                    if (keep && elig) { fast = true; keep = false; fast_chain[it] = (m & (m - 1)) ? (int)(0x80000000u | m) : c1; }
+                } else {
                 const DRay r = root_ray_for_cull(S, g, first, k, rays_org, rays_dir);
                 if (tm != 255 && g.tile_cand) {
                     /* the tile's list holds every child a ray through the tile can touch: test their boxes, no BVH walk */
@@ -444,6 +491,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 #ifdef RT_NH_HIST
                     if (keep) atomicAdd(&P.counters[CTR_PROF + 8], 1);
 #endif
+                }
                 }
             }
             if (!keep && !fast && !(masked && g.mask_skips_rgb)) {

@@ -961,3 +961,17 @@ def test_fast_path_is_invisible(gpu, scene):
     gpu.set_options({"level_sync": 0})
     d, sd = fast_scene.render(480, 270, 16)
     assert np.array_equal(c, d) and sc.rays() == sd.rays()
+    # the generator's box tests in single precision against grown boxes (option cull_f32, read at upload) or in double: the same
+    # frames; the float test may keep a sample the double test drops (it then misses in the kernel that takes it), never the reverse
+    gpu.set_options({"cull_f32": 0})
+    try:
+        f64_scene = gpu.GpuScene(fs.desc)
+    finally:
+        gpu.set_options({"cull_f32": 1})
+    for (w, h, spp) in ((960, 540, 16), (333, 187, 9), (1920, 1080, 4)):
+        a, sa = fast_scene.render(w, h, spp)
+        b, sb = f64_scene.render(w, h, spp)
+        assert np.array_equal(a, b), (w, h, spp)
+        assert sa.rays() == sb.rays()
+        assert sa.rays_fast + sa.rays_visual0 >= sb.rays_fast + sb.rays_visual0
+        assert sa.rays_fast + sa.rays_visual0 <= 1.02 * (sb.rays_fast + sb.rays_visual0) + 64
