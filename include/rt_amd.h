@@ -33,7 +33,9 @@ const char *rt_last_error(void);
 
 /* Flatten + upload a scene to the current HIP device.  Replaces the implicit "scene is a pointer
    graph reachable from RayTracer" of the reference (RayTracer2020.h:188-202); the description must
-   be the graph as it stands after psModel->Optimize() (TestScene.cpp:1614). */
+   be the graph as it stands after psModel->Optimize() (TestScene.cpp:1614).  The planet image maps a scene's textures read
+   (RtSceneDesc.images: the file-static Images of TextureMaps.cpp:945-947 as Image::ReadBMP leaves them) are copied to the
+   device here; a planet texture whose images are missing is RT_ERR_INVALID. */
 int  rt_scene_upload(const RtSceneDesc *desc, rt_scene **out);
 void rt_scene_free(rt_scene *s);
 
@@ -142,8 +144,10 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
 /* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 33,552,000 = 20970 sampling tiles; the queues of a pass take about 2 KB of HBM per sample),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
    "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
-   "fuse_splat" (0/1, default 0: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled
-   image staying in LDS -- 10.6 GB less HBM at 4K / 64 spp, about 4 % slower -- or in two kernels through memory; same result),
+   "fuse_splat" (0/1/2, default 2: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled
+   image staying in LDS; 2: that kernel honours the need map (tiles that cannot matter are neither gathered nor filtered), deals
+   pixels of equal tile position to a wave's lanes and reads the splat table's rows from LDS; 1: the first fused kernel, without
+   the need map; 0: two kernels through memory; same result),
    "persistent", "lds_chains" (0/1: launch geometry / chain records in LDS, for A/B runs),
    "lds_tables" (0/1/2, default 1; 2 = the program and region tables alone when the rest does not fit: stage the scene's small tables -- program, boxes, affines, materials, surfaces, region tables -- in LDS
    next to the chain records when they fit; takes effect at rt_scene_upload),
@@ -156,7 +160,7 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    they hold -- in the splat gather (1) and in the two resampling passes (2); 3: the gather does not even write them and the
    row pass takes them as the zeros they would hold; results do not depend on it),
    "tile_cand" (0/1/2, default 2: the same pass lists, per tile, the children of the root union region a ray through the
-   tile can touch -- up to 8; 1: the generator tests those boxes instead of walking the BVH per sample, 2: so does the
+   tile can touch -- up to 16; 1: the generator tests those boxes instead of walking the BVH per sample, 2: so does the
    tracing kernel for primary rays; results do not depend on it),
    "full_waves" (1 / 2, default 2: waves per SIMD the kernels for the rare features -- tori, meshes, textures,
    propagators, spectral metals -- are built for; two hide the latency of mesh walks, one has no register spills; at
@@ -169,6 +173,12 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    "fast_path" (0/1, default 1: primary rays that can only touch bare chains of the root union region -- two-root primitives
    without texture call-outs, propagators or spectral metals -- are traced by k_fast: no interpreter, no hit arena, hits in
    registers, and no frame where neither a shadow ray nor a child ray is needed; at rt_scene_upload; results do not depend on it),
+   "fast_split" (0/1, default 1: the fast path as two kernels -- k_fast_hit: ray, chain, hits, where the walk stops -> a 44-byte
+   boundary record per queue entry; k_fast_shade: light loop and RGB from the record -- each at a higher occupancy than the one
+   kernel k_fast (0); results do not depend on it),
+   "cull_f32" (0/1, default 1: the generator tests the boxes of a sample tile's list in single precision against boxes grown by
+   1e-4 of the scene's scale; it can only keep more samples than the double test, which then miss in the kernel that takes them;
+   at rt_scene_upload; results do not depend on it),
    "level_sync" (0/1, default 0: 1 makes every pass wait for the host after every level, also where the device-side
    bounds make that unnecessary; for A/B runs),
    "mesh_pre" (0/1/2, default 2: scenes with exactly one mesh instruction walk their rays through the mesh's BVH in a kernel of

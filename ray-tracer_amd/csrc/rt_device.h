@@ -29,7 +29,12 @@
 #define RT_MAX_DEPTH        11      /* Shade.cpp:420 */
 #define RT_MAX_CAND         64      /* children of one union region whose boxes a ray may touch */
 #define RT_MAX_REGION_DEPTH 4       /* nested union regions */
-#define RT_TILE_CAND        8       /* children of the root region listed per sampling tile (k_tile_mask) */
+#ifndef RT_TILE_CAND
+#define RT_TILE_CAND        16      /* children of the root region listed per sampling tile (k_tile_mask); 8 left 1 % of S0's primary rays to the interpreter (tiles near the horizon that see more than eight spheres): 23.4 vs 21.8 ms per 4K / 64 frame */
+#endif
+#if RT_TILE_CAND > 31
+#error "a queue entry of the fast path holds the touched entries of a tile's list as bits 0..30"
+#endif
 #define RT_REGION_MIN       4       /* unions of fewer children stay plain binary code */
 
 enum RtOp {

@@ -1243,7 +1243,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
                behind it matters: the ray is finished from that one hit.  Anything else is handed to the interpreter. */
             const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
             double t_best = RT_INFINITY, t_next = RT_INFINITY;
-            for (unsigned m = (unsigned)code & 0xFFu; m; m &= m - 1) {
+            for (unsigned m = (unsigned)code & 0x7FFFFFFFu; m; m &= m - 1) {     /* bit q: entry q of the tile's list (RT_TILE_CAND <= 31) */
                 const RtChain &ch = chains[S.root_fast[tl[__builtin_ctz(m)]]];
                 RegEmit T;
                 fast_chain_hits(S, ch, ray, T);
@@ -1400,7 +1400,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTA_THREADS, 1) 
             /* several: the nearest first hit decides when every list starts ahead of the origin (see k_fast) */
             const unsigned short *tl = g.tile_cand + (size_t)tile * RT_TILE_CAND;
             double t_best = RT_INFINITY, t_next = RT_INFINITY;
-            for (unsigned m = (unsigned)code & 0xFFu; m; m &= m - 1) {
+            for (unsigned m = (unsigned)code & 0x7FFFFFFFu; m; m &= m - 1) {     /* bit q: entry q of the tile's list (RT_TILE_CAND <= 31) */
                 const RtChain &ch = chains[S.root_fast[tl[__builtin_ctz(m)]]];
                 RegEmit T;
                 fast_chain_hits(S, ch, ray, T);
