@@ -241,13 +241,18 @@ RT_DEV DRay root_ray_for_cull(const RtDevScene &S, const RtSampleGrid &g, int64_
  * orthographic camera the origins move instead, and the boxes are inflated by that much).  A box is replaced by its
  * bounding sphere: cone and sphere do not meet  =>  no ray of the tile meets the box.  Conservative by construction,
  * with slack far above the rounding of the sample positions. */
-RT_DEV bool cone_may_touch(const D3 &o, const D3 &d /*unit*/, double cos_t, double sin_t, double grow, const double lo[3], const double hi[3])
+/* lens, inv_fd (ApertureCamera, Cameras.h:52-67): a ray starts at most `lens` away from the apex and passes through the point of the
+   central ray -- the one the cone is about -- at the focus distance, so at distance l along it is at most lens * |1 - l / fd| away from
+   the central ray's point: the sphere grows by lens * max(1, (dist + r) / fd) */
+RT_DEV bool cone_may_touch(const D3 &o, const D3 &d /*unit*/, double cos_t, double sin_t, double grow, const double lo[3], const double hi[3],
+                           const double lens = 0.0, const double inv_fd = 0.0)
 {
     const D3 c = d3(0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]));
     const D3 h = d3(0.5 * (hi[0] - lo[0]), 0.5 * (hi[1] - lo[1]), 0.5 * (hi[2] - lo[2]));
-    const double r = sqrt(dot(h, h)) * (1.0 + 1e-9) + grow + 1e-9;
+    double r = sqrt(dot(h, h)) * (1.0 + 1e-9) + grow + 1e-9;
     if (!(r < 1e100)) return true;                      /* unbounded or not a number: cannot exclude */
     const D3 v = c - o;
+    if (lens > 0.0) r += lens * fmax(1.0, (sqrt(dot(v, v)) + r) * inv_fd) * (1.0 + 1e-9);
     const double dist2 = dot(v, v);
     if (!(dist2 > r * r)) return true;                  /* the apex is inside the sphere */
     const double dist = sqrt(dist2), sin_b = r / dist, cos_b = sqrt(fmax(0.0, 1.0 - sin_b * sin_b));
@@ -275,7 +280,14 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
         if (m > grow) grow = m;
     }
     cos_t = cos_t - 1e-12 - 1e-6 * (1.0 - cos_t);       /* widen the cone a little */
-    if (!(cos_t > 0.0)) { mask[t] = 1; return; }        /* absurdly wide tile: no statement */
+    if (!(cos_t > 0.0)) { mask[t] = 255; return; }      /* absurdly wide tile: no statement */
+    double lens = 0.0, inv_fd = 0.0;
+    if (S.cam.type == RT_CAM_APERTURE) {                /* lens points: org + vX u + vY v with |u|, |v| <= 1 */
+        lens = (sqrt(S.cam.vX[0] * S.cam.vX[0] + S.cam.vX[1] * S.cam.vX[1] + S.cam.vX[2] * S.cam.vX[2]) +
+                sqrt(S.cam.vY[0] * S.cam.vY[0] + S.cam.vY[1] * S.cam.vY[1] + S.cam.vY[2] * S.cam.vY[2])) * (1.0 + 1e-9) + 1e-12;
+        if (!(S.cam.focus_distance > 0.0)) { mask[t] = 255; return; }
+        inv_fd = (1.0 + 1e-9) / S.cam.focus_distance;
+    }
     const double sin_t = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
     grow *= 1.0 + 1e-6;
     /* 0 = nothing can be touched; 1..RT_TILE_CAND = that many root-region children listed in cand (all of them, ascending);
@@ -283,7 +295,7 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
     int n = 0;
     bool walk = false;
     unsigned short list[RT_TILE_CAND];
-    if (S.root_cull == 2) walk = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi);
+    if (S.root_cull == 2) walk = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi, lens, inv_fd);
     else if (S.root_cull == 1) {
         const RtRegion &rg = S.regions[S.root_cull_arg];
         if (rg.n_always > 0) walk = true;
@@ -294,7 +306,7 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
                 for (int k = 0; k < 4 && !walk; k++) {
                     if (nd.child[k] == RT_BVH_EMPTY) continue;
                     const double lo[3] = { nd.lo[0][k], nd.lo[1][k], nd.lo[2][k] }, hi[3] = { nd.hi[0][k], nd.hi[1][k], nd.hi[2][k] };
-                    if (!cone_may_touch(rc.org, dc, cos_t, sin_t, grow, lo, hi)) continue;
+                    if (!cone_may_touch(rc.org, dc, cos_t, sin_t, grow, lo, hi, lens, inv_fd)) continue;
                     if (nd.child[k] < 0) {
                         if (n < RT_TILE_CAND && cand) list[n++] = (unsigned short)(~nd.child[k]);
                         else walk = true;
@@ -1226,7 +1238,9 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
                 aux[2] = 2.0 * S.blue[2 * q2] - 1.0;
                 aux[3] = 2.0 * S.blue[2 * q2 + 1] - 1.0;
             }
-            ray = camera_emit(S.cam, v0, v1, 0.0, 0.0);
+            double uC = 0.0, vC = 0.0;
+            if (S.cam.type == RT_CAM_APERTURE) { const int q3 = S.qi3[i]; uC = 2.0 * S.blue[2 * q3] - 1.0; vC = 2.0 * S.blue[2 * q3 + 1] - 1.0; }
+            ray = camera_emit(S.cam, v0, v1, uC, vC);
         }
         RegEmit H;
         H.L = 0; H.minv_own = 0;
@@ -1335,7 +1349,12 @@ RT_DEV DRay fast_ray(const RtDevScene &S, const RtSampleGrid &g, const int64_t f
     const double vtx = (double)tx * (double)RT_BLUE_NSQRT, vty = (double)ty * (double)RT_BLUE_NSQRT;
     const double vx = S.blue[2 * i] * (double)RT_BLUE_NSQRT + vtx, vy = S.blue[2 * i + 1] * (double)RT_BLUE_NSQRT + vty;
     const double v0 = (vx + g.adjust_x) / g.size, v1 = (vy + g.adjust_y) / g.size;
-    return camera_emit(S.cam, v0, v1, 0.0, 0.0);
+    double uC = 0.0, vC = 0.0;
+    if (S.cam.type == RT_CAM_APERTURE) {        /* the lens pair of sample_at: aux[0], aux[1] */
+        const int q3 = S.qi3[i];
+        uC = 2.0 * S.blue[2 * q3] - 1.0; vC = 2.0 * S.blue[2 * q3 + 1] - 1.0;
+    }
+    return camera_emit(S.cam, v0, v1, uC, vC);
 }
 RT_DEV void fast_aux(const RtDevScene &S, const int i, double *aux)
 {

@@ -924,6 +924,36 @@ def test_launch_and_staging_options_are_invisible(gpu, scene, name, off, on):
         L.rt_set_option(name.encode(), on)
 
 
+SCENE_ROW_DOF = SCENE_ROW.replace("(camera stereographic 0 0 9 70)", "(camera aperture 2.0 12.0 0.4 -0.3 9 70)")
+
+
+@pytest.mark.gpu
+def test_aperture_camera_gets_tile_lists_and_the_fast_path(gpu, oracle):
+    """ApertureCamera (Cameras.h:52-67) with a root union region: the tile mask grows every box by what the lens can move a ray
+    (k_tile_mask), so the generator's cull, the tile lists and the fast path serve depth-of-field scenes too (option
+    tile_aperture).  Same frames as the oracle and as the path without the mask; the lens is wide enough to blur the row."""
+    assert SCENE_ROW_DOF != SCENE_ROW
+    opt, raw, g, o = _pair(gpu, oracle, SCENE_ROW_DOF, "")
+    sharp_fs = gpu.FrontScene(SCENE_ROW, "", optimize=True)        # (kept alive: the description points into it)
+    sharp = gpu.GpuScene(sharp_fs.desc)
+    for (w, h, spp) in ((160, 96, 16), (333, 187, 4)):
+        img, st = g.render(w, h, spp)
+        ost = gpu.RtStats()
+        ref, _, n = o.render(w, h, spp, gpu.RtRenderDesc(w, h, float(spp), 0, 0), ost, threads=8)
+        assert st.samples == n and (st.rays_primary, st.rays_shadow, st.rays_secondary) == (ost.rays_primary, ost.rays_shadow, ost.rays_secondary)
+        assert np.array_equal(img, ref)
+        assert st.rays_fast > 0 and st.rays_fast + st.rays_visual0 < st.rays_primary        # fast path and generator cull both at work
+        gpu.set_options({"tile_aperture": 0})
+        try:
+            img0, st0 = g.render(w, h, spp)
+        finally:
+            gpu.set_options({"tile_aperture": 1})
+        assert np.array_equal(img0, img) and st0.rays() == st.rays() and st0.rays_fast == 0
+    a, _ = g.render(160, 96, 16)
+    b, _ = sharp.render(160, 96, 16)
+    assert np.abs(a - b).max() > 0.05
+
+
 SCENE_POLISHED_ROW = SCENE_ROW.replace("plastic none none (sphere)", "plastic none none (surface polished none (sphere))")
 
 
