@@ -482,8 +482,12 @@ def roofline(rt, gs, fs, W, H, spp, st, steps, rays_fast_total, workload):
     visual_rays = max(1, st.rays_primary + st.rays_secondary)
     if fast_launches > 0 and rays_fast_total > 0.5 * (rays_fast_total + st.rays_visual0 * steps):
         kernel, ms_per_launch, rays_per_launch = "k_fast", fast_ms / fast_launches, rays_fast_total / fast_launches
-        bytes_per_ray = 8.0 + 12.0
-        events["box_tests_done"] = "none in this kernel: the generator tests the <= 8 boxes of the sample tile's list (k_tile_mask), no BVH walk"
+        # one launch = the pair k_fast_hit + k_fast_shade (option fast_split, the default): 8-byte queue entry in, a 44-byte boundary
+        # record written and read back, 12 bytes of RGB out; the single kernel k_fast (fast_split = 0): 8 in, 12 out
+        split = rt.get_options().get("fast_split", 1) == 1
+        bytes_per_ray = (8.0 + 44.0 + 44.0 + 12.0) if split else (8.0 + 12.0)
+        events["kernels_per_launch"] = "k_fast_hit + k_fast_shade (timed as one pair)" if split else "k_fast"
+        events["box_tests_done"] = "none in these kernels: the generator tests the <= 16 boxes of the sample tile's list (k_tile_mask), no BVH walk"
     else:
         if ms_per_launch <= 0:
             return dict(empty, note="no tracing kernel launch was timed")

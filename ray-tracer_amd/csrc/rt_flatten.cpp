@@ -545,8 +545,12 @@ struct Flattener {
             memset(&zero, 0, sizeof zero);
             o.region_child_boxes.resize(o.region_child_pc.size(), zero);
             for (int k = 0; k < K; k++) {
-                if (boxes[k].empty || !boxes[k].finite()) continue;
+                if (boxes[k].empty) continue;
                 RtBox &rb = o.region_child_boxes[rg.child_pc0 + k];
+                if (!boxes[k].finite()) {           /* an "always" child (a sky dome): a box every ray meets, for the code that tests a sample tile's list */
+                    for (int d = 0; d < 3; d++) { rb.lo[d] = -1.0e37; rb.hi[d] = 1.0e37; }
+                    continue;
+                }
                 for (int d = 0; d < 3; d++) {           /* the padding of a BVH leaf (build_bvh_once) */
                     double e = 1e-6 * (fabs(boxes[k].hi[d] - boxes[k].lo[d]) + fabs(boxes[k].lo[d]) + fabs(boxes[k].hi[d])) + 1e-9;
                     rb.lo[d] = boxes[k].lo[d] - e; rb.hi[d] = boxes[k].hi[d] + e;
@@ -805,8 +809,62 @@ struct Flattener {
 
 } // namespace
 
-int rt_flatten_scene(const RtSceneDesc *d, RtFlatScene &out, std::string &err, bool with_bounds)
+/* Wrappers pushed down through unions (option push_wrappers), on a private copy of the node array:
+     Surface(A u B)  = Surface(A) u Surface(B)      -- Surface::Intersect (Solids.cpp:1498-1519) labels every hit with t != 0 of the list
+                                                        it is handed; a merge (Solids.cpp:1014-1058) selects hits and rewrites materials
+                                                        and never reads the surface, so labelling before or after it is the same;
+     Material(A u B) = Material(A) u Material(B)    -- when A u B holds no Material of its own and the density is positive:
+                                                        Material::Intersect (Solids.cpp:1466-1487) renames every dense hit, and below
+                                                        it every dense hit is neutronium, so the merge compares equal densities on
+                                                        either side of the rewrite, keeps the same hits and hands back the same name.
+   What it buys: a scene like Surface(Union of nine objects) + floor, or Surface(Material(cage of 42 struts)) + floor + dome, becomes
+   ONE union region at the root -- the generator's cull, the per-tile candidate lists and the fast path apply -- instead of a wrapper
+   around a nested region.  Hit lists are unchanged (the oracle sees the description as it came). */
+static int g_push_wrappers = 0;
+void rt_flatten_set_push_wrappers(int on) { g_push_wrappers = on ? 1 : 0; }
+namespace {
+struct WrapperPush {
+    std::vector<RtNode> &nd;
+    const double *data;
+    std::vector<signed char> has_mat;       /* memo: subtree holds a Material (-1 unknown) */
+    WrapperPush(std::vector<RtNode> &n, const double *dd) : nd(n), data(dd), has_mat(n.size(), -1) {}
+    bool holds_material(int i)
+    {
+        if (i < 0) return false;
+        if ((size_t)i < has_mat.size() && has_mat[i] >= 0) return has_mat[i] != 0;
+        const bool r = nd[i].type == RT_NODE_MATERIAL || holds_material(nd[i].left) || holds_material(nd[i].right);
+        if ((size_t)i < has_mat.size()) has_mat[i] = r ? 1 : 0;
+        return r;
+    }
+    void wrapper(int i)                     /* node i is a wrapper whose subtree has been visited: push it down while it sits on a union */
+    {
+        if (nd[i].type != RT_NODE_SURFACE && nd[i].type != RT_NODE_MATERIAL) return;
+        const int c = nd[i].left;
+        if (c < 0 || (nd[c].type != RT_NODE_UNION && nd[c].type != RT_NODE_TOPUNION) || nd[c].left < 0 || nd[c].right < 0) return;
+        if (nd[i].type == RT_NODE_MATERIAL && (!(data[nd[i].data] > 0.0) || holds_material(c))) return;
+        RtNode w1 = nd[i], w2 = nd[i], u = nd[c];
+        w1.left = u.left; w2.left = u.right;
+        const int i1 = (int)nd.size();
+        nd.push_back(w1); nd.push_back(w2);
+        u.left = i1; u.right = i1 + 1;
+        nd[i] = u;                          /* the wrapper's slot becomes the union (its parent keeps pointing here) */
+        wrapper(i1); wrapper(i1 + 1);
+    }
+    void visit(int i, int depth)
+    {
+        if (i < 0 || depth > 4096) return;
+        const int l = nd[i].left, r = nd[i].right;
+        visit(l, depth + 1);
+        const int t = nd[i].type;
+        if (t == RT_NODE_UNION || t == RT_NODE_TOPUNION || t == RT_NODE_INTERSECTION || t == RT_NODE_DIFFERENCE) visit(r, depth + 1);
+        wrapper(i);
+    }
+};
+}
+
+int rt_flatten_scene(const RtSceneDesc *d_in, RtFlatScene &out, std::string &err, bool with_bounds)
 {
+    const RtSceneDesc *d = d_in;
     if (!d || d->n_nodes < 0 || (d->n_nodes && !d->nodes)) { err = "null scene description"; return RT_ERR_INVALID; }
     for (int i = 0; i < d->n_nodes; i++) {
         const RtNode &n = d->nodes[i];
@@ -815,6 +873,19 @@ int rt_flatten_scene(const RtSceneDesc *d, RtFlatScene &out, std::string &err, b
         if (n.right >= 0 && n.right <= i) { err = "scene is not a tree in pre-order"; return RT_ERR_INVALID; }
     }
     if (d->n_lights > RT_MAX_LIGHTS) { err = "more than RT_MAX_LIGHTS point lights"; return RT_ERR_UNSUPPORTED; }
+    std::vector<RtNode> pushed;
+    RtSceneDesc d2;
+    if (g_push_wrappers && with_bounds && d->n_nodes > 0 && d->root >= 0) {
+        pushed.assign(d->nodes, d->nodes + d->n_nodes);
+        pushed.reserve((size_t)d->n_nodes * 2 + 16);
+        WrapperPush wp(pushed, d->data);
+        wp.visit(d->root, 0);
+        if ((int)pushed.size() != d->n_nodes) {
+            d2 = *d;
+            d2.nodes = &pushed[0]; d2.n_nodes = (int)pushed.size();
+            d = &d2;
+        }
+    }
     Flattener f(d, out, err, with_bounds);
     f.node_affine.assign((size_t)(d->n_nodes > 0 ? d->n_nodes : 1), -1);
     /* built-in materials / surfaces (Solids.cpp:1463-1464, :169) */

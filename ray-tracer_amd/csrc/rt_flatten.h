@@ -30,3 +30,5 @@ struct RtFlatScene {
 
 /* returns 0 or an RT_ERR_* code with a message in err */
 int rt_flatten_scene(const RtSceneDesc *d, RtFlatScene &out, std::string &err, bool with_bounds);
+/* option push_wrappers (rt_flatten.cpp): Surface / Material wrappers above a union are pushed down to its operands (default on) */
+void rt_flatten_set_push_wrappers(int on);

@@ -298,8 +298,12 @@ __global__ void __launch_bounds__(256) k_tile_mask(const RtDevScene Sv, RtSample
     if (S.root_cull == 2) walk = cone_may_touch(rc.org, dc, cos_t, sin_t, grow, S.boxes[S.root_cull_arg].lo, S.boxes[S.root_cull_arg].hi, lens, inv_fd);
     else if (S.root_cull == 1) {
         const RtRegion &rg = S.regions[S.root_cull_arg];
-        if (rg.n_always > 0) walk = true;
-        else if (rg.bvh_root >= 0) {
+        /* children without a finite box (a sky dome) are on every tile's list; without lists they leave nothing to say */
+        for (int q = 0; q < rg.n_always; q++) {
+            if (n < RT_TILE_CAND && cand) list[n++] = (unsigned short)S.region_always[rg.always0 + q];
+            else walk = true;
+        }
+        if (!walk && rg.bvh_root >= 0) {
             int stack[RT_BVH_STACK], sp = 0, node = rg.bvh_root;
             for (;;) {
                 const RtBvhNode &nd = S.bvh[node];

@@ -954,6 +954,54 @@ def test_aperture_camera_gets_tile_lists_and_the_fast_path(gpu, oracle):
     assert np.abs(a - b).max() > 0.05
 
 
+SCENE_WRAPPED_ROW = """(scene
+ (model (makeunion
+   (surface shiny none (material 0.9 auto g_sOrange plastic none none (makeunion
+     (translate -2 0 0 (scale 0.5 0.5 0.5 (sphere)))
+     (translate -1.4 0.2 0 (scale 0.5 0.5 0.5 (cube)))
+     (translate -0.9 -0.3 -1 (rotate 0.3 0.2 0 (scale 0.4 0.4 0.8 (cylinder))))
+     (translate -2.2 0.9 -1 (scale 0.5 0.5 0.5 (dodecahedron))))))
+   (surface smooth none (makeunion
+     (translate 1 0 0 (scale 0.6 0.6 0.6 (material 0.4 auto g_sYellow plastic none none (sphere))))
+     (translate 1.5 0.3 0.2 (scale 0.5 0.5 0.5 (material 0.8 auto g_sCyan metal none none (cube))))
+     (translate 2.2 -0.4 -1 (scale 0.5 0.5 0.5 (material 0.6 auto g_sRed plastic none none (sphere))))
+     (translate 1.8 1.0 -2 (scale 0.6 0.6 0.6 (material 0.3 auto g_sGreen plastic none none (icosahedron))))))
+   (translate 0 1.6 -3 (scale 8 0.2 8 (material 0.9 auto g_sEqualWhite plastic none none (cube))))))
+ (ambient (scale (blackbody 6500) 0.02))
+ (pointlight -10 -10 10 (scale (blackbody 6500) 500))
+ (camera stereographic 0 0 9 40)
+ (sampler fastblue))"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["S1", "S2", SCENE_WRAPPED_ROW], ids=["S1", "S2", "wrapped_row"])
+def test_wrapper_push_down_is_invisible(gpu, oracle, scene):
+    """Option push_wrappers (rt_flatten.cpp): Surface(A u B) = Surface(A) u Surface(B), and Material(A u B) = Material(A) u Material(B)
+    where A u B holds no Material of its own -- the rewritten tree renders the same frame with the same ray counts, and the frame
+    equals the oracle's, which sees the description as it came.  The wrapped scene: a Surface over a Material over a union of bare,
+    overlapping solids (both go down), a Surface over a union of solids with materials of their own (overlapping, different
+    densities), and a floor: nine children at the root once the wrappers are down."""
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    raw = gpu.FrontScene(scene, "fastblue", optimize=False)
+    plain = gpu.GpuScene(fs.desc)
+    gpu.set_options({"push_wrappers": 1})
+    try:
+        pushed = gpu.GpuScene(fs.desc)
+    finally:
+        gpu.set_options({"push_wrappers": 0})
+    for (w, h, spp) in ((192, 108, 4), (97, 61, 9)):
+        a, sa = plain.render(w, h, spp)
+        b, sb = pushed.render(w, h, spp)
+        assert np.array_equal(a, b) and (sa.rays_primary, sa.rays_shadow, sa.rays_secondary) == (sb.rays_primary, sb.rays_shadow, sb.rays_secondary)
+    if scene == SCENE_WRAPPED_ROW:
+        ost = gpu.RtStats()
+        ref, _, n = oracle.OracleScene(raw.desc).render(192, 108, 4, gpu.RtRenderDesc(192, 108, 4.0, 0, 0), ost, threads=8)
+        b, sb = pushed.render(192, 108, 4)
+        assert np.array_equal(b, ref) and sb.rays() == ost.rays() and float(ref.max()) > 0
+        a, sa = plain.render(192, 108, 4)
+        assert sa.rays_fast == 0 and sb.rays_fast > 0 and sb.rays_fast + sb.rays_visual0 < sb.rays_primary   # the root region brings cull and fast path
+
+
 SCENE_POLISHED_ROW = SCENE_ROW.replace("plastic none none (sphere)", "plastic none none (surface polished none (sphere))")
 
 

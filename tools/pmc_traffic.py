@@ -33,11 +33,13 @@ txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 7:
     open(sys.argv[7], "w").write(txt + "\n")
-key = [k for k in fetch if k.startswith(kernel)]
+key = sorted(k for k in fetch if k.startswith(kernel))
 if key:
-    k = key[0]
-    n = max(nf[k], nw.get(k, 0), 1)
-    rd, wr = 2.0 * 1024.0 * fetch[k], 1024.0 * write.get(k, 0.0)
+    # one "launch" of bench.py's roofline kernel may be a pair of kernels (k_fast = k_fast_hit + k_fast_shade): their traffic is summed
+    # and divided by the launches of ONE of them
+    n = max(max(nf[k], nw.get(k, 0), 1) for k in key)
+    rd = sum(2.0 * 1024.0 * fetch[k] for k in key)
+    wr = sum(1024.0 * write.get(k, 0.0) for k in key)
     r = b["roofline"]
     from bench import library_fingerprint
     json.dump({"library_fingerprint": library_fingerprint(),"workload": b["config"]["workload"].split(" (")[0], "kernel": kernel, "launches_per_frame": n,
