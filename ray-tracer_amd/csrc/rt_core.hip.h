@@ -1126,14 +1126,7 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    cost the tightly budgeted LITE kernels spills (S1 / S2 ran 6-8 % slower with the code merely present). */
 /* MESHPRE (LITE only): the scene's one mesh instruction is served from pre-walked crossings (k_mesh_cross ran over every ray
    of the level before this kernel) instead of handing the ray over */
-/* scheduling classes of the opcodes (3 bits each, FULL kernels): 0 control flow and frames, 1 relabelling, 2 merges, 3 end of a
-   region child (its folds), 4 region entry (BVH walk), 5 bare primitives, 6 chains, 7 tori and meshes */
-#define RT_SCHED_CLS(op, c) ((unsigned long long)(c) << (3 * (op)))
-#define RT_SCHED_CLASSES (RT_SCHED_CLS(OP_END, 0) | RT_SCHED_CLS(OP_BOUND, 0) | RT_SCHED_CLS(OP_REFBOX, 0) | RT_SCHED_CLS(OP_PUSH_AFFINE, 0) | RT_SCHED_CLS(OP_POP_AFFINE, 0) | \
-                          RT_SCHED_CLS(OP_SKIP_EMPTY, 0) | RT_SCHED_CLS(OP_RETAG, 1) | RT_SCHED_CLS(OP_MATERIAL, 1) | RT_SCHED_CLS(OP_SURFACE, 1) | \
-                          RT_SCHED_CLS(OP_UNION, 2) | RT_SCHED_CLS(OP_INTER, 2) | RT_SCHED_CLS(OP_DIFF, 2) | RT_SCHED_CLS(OP_ANGCLIP, 2) | RT_SCHED_CLS(OP_RET, 3) | \
-                          RT_SCHED_CLS(OP_REGION, 4) | RT_SCHED_CLS(OP_QUADRIC, 5) | RT_SCHED_CLS(OP_POLY, 5) | RT_SCHED_CLS(OP_SLAB, 5) | RT_SCHED_CLS(OP_CHAIN, 6) | \
-                          RT_SCHED_CLS(OP_TORUS, 7) | RT_SCHED_CLS(OP_MESH, 7))
+/* SCHED (FULL kernels of long programs, levels behind the first): the lanes of a wave run in the order of their pc -- see the loop */
 template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false, bool SCHED = false, class AR>
 __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, AR &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
@@ -1161,6 +1154,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     int pc = 0;
     RtInstr in;
     bool fetch = true;     /* (SCHED) this lane ran its instruction in the round before */
+    const int pc_bits = 31 - __clz((S.n_prog + S.n_root_alt * 2 + 2) | 1);      /* top bit a pc can have (the root's single-chain copies sit behind the program) */
 #ifdef RT_MESH_COUNT
     long long cnt_t0 = 0; int cnt_op = 0;
 #endif
@@ -1180,6 +1174,13 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
     MESH_COUNT(LITE ? 19 : 11, 1);
 #endif
     for (;;) {
+#ifdef RT_MESH_COUNT
+        {   /* lanes still in the loop this round, running or waiting for their class: against the lanes that run (+2), the share of
+               class serialisation; against 64, the share of rays of unequal length */
+            const unsigned long long alive = __ballot(1);
+            if ((__ffsll((long long)alive) - 1) == (int)(threadIdx.x & 63)) { atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 4], (unsigned long long)__popcll(alive)); atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 5], 1ull); }
+        }
+#endif
         if (!SCHED || fetch) { in = S.prog[pc]; pc++; }
 #ifdef RT_MESH_COUNT
         if constexpr (SCHED) {
@@ -1192,16 +1193,25 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         }
 #endif
         if constexpr (SCHED) {
-            /* the lanes of a wave sit at different instructions: instead of running every opcode present one after the other
-               with a handful of lanes each, a round runs ONE class of opcodes -- the cheapest present -- and the other lanes
-               wait, so that they gather at the expensive instructions (primitives, merges) and run those together.  A lane
-               still executes its own instructions in its own order: results do not depend on this */
-            const int cls = (int)((RT_SCHED_CLASSES >> (3 * in.op)) & 7ull);
+            /* The lanes of a wave sit at different instructions.  Every jump of a program goes FORWARD (a box that is missed, an empty
+               operand, the next candidate of a region, a region's end), so lanes that part ways meet again further down -- if the
+               ones ahead wait.  A round therefore runs the lanes at the SMALLEST pc and nobody else: they execute one and the same
+               instruction (one opcode, one box, one affine, one chain record for the whole round), and the others join them when
+               the round's lanes reach their pc.  Round 2 ran the cheapest CLASS of opcodes present instead (lanes at different
+               instructions of one class together): S4 took 166.6 rounds per 64 rays with 27.5 lanes running; this order takes 88.6
+               with 51.7 (tools/diverge_count.py) -- and because a round's lanes now touch the same slots of their hit arenas, those
+               live in private memory again, whose lane-interleaved layout coalesces such accesses (the pool of round 2, built for
+               seven running lanes, is gone: S4 1080p / 4 spp 757 -> 613 ms by the order alone, -> 460 with private arenas).
+               A lane still executes its own instructions in its own order: results do not depend on any of this.  The lane at
+               the smallest pc always runs, so every lane finishes whatever the program looks like. */
             fetch = true;
-            if (__ballot(cls != __builtin_amdgcn_readfirstlane(cls))) {        /* (a wave of like rays skips all this) */
-                int run = 0;
-                while (!__ballot(cls == run)) run++;
-                fetch = cls == run;
+            if (__ballot(pc != __builtin_amdgcn_readfirstlane(pc))) {          /* (a wave of like rays skips all this) */
+                int mp = 0;             /* the smallest pc among the lanes in the loop, bit by bit from the top (finished lanes hold no value) */
+                for (int bit = pc_bits; bit >= 0; --bit) {
+                    const bool cand = (pc >> (bit + 1)) == (mp >> (bit + 1));
+                    if (!__ballot(cand && !((pc >> bit) & 1))) mp |= 1 << bit;
+                }
+                fetch = pc == mp;
                 if (!fetch) continue;
             }
         }

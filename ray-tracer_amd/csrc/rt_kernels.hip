@@ -867,8 +867,12 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
         ray.dir = d3_fetch(P.f_ray, P.fcap, 3, f);
         int root = P.f_root[f];
         aux_load<LITE>(S, P, root, aux);
+#ifdef RT_SCHED_POOL     /* round 2's layout for the scheduled kernels: per-lane arenas in a pool in global memory (see intersect_scene) */
         ArenaT<SCHED> A;
         if constexpr (SCHED) A.bind(P.arena_pool, (size_t)(blockIdx.x * blockDim.x + threadIdx.x));
+#else
+        ArenaT<false> A;
+#endif
         int start;
         const unsigned short *tile_list = 0;
         int tile_n = 0, one = -1;
@@ -1826,8 +1830,12 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         aux_load<LITE>(S, P, root, aux);
         double r2 = dot(ray.dir, ray.dir);
         Spec E = spec_div(spec_load(l.flux), 4.0 * RT_PI * r2);
+#ifdef RT_SCHED_POOL     /* round 2's layout for the scheduled kernels: per-lane arenas in a pool in global memory (see intersect_scene) */
         ArenaT<SCHED> A;
         if constexpr (SCHED) A.bind(P.arena_pool, (size_t)(blockIdx.x * blockDim.x + threadIdx.x));
+#else
+        ArenaT<false> A;
+#endif
         int start;
         int count = intersect_scene<LITE, CH_LDS, false, MESHPRE, SCHED>(S, lds, ray, 1.0, A, start, 0, 0, -1,
                                                                   (LITE && MESHPRE) ? s : ((!LITE && !direct) ? (P.mx_all ? s : wbase + wlane) : -1));

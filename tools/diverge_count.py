@@ -24,6 +24,8 @@ torch.cuda.synchronize()
 L.rt_debug_counts32(out, 1)
 for name, b in (("FULL", 8), ("LITE", 16)):
     it, nd, act, rays = out[b], out[b + 1], out[b + 2], out[b + 3]
+    if out[b + 5]:
+        print("%s %s: lanes still in the loop per pass of the loop %.1f of 64 (running or waiting for their class; %d passes)" % (scene, name, out[b + 4] / float(out[b + 5]), out[b + 5]))
     if it:
         print("%s %s: %d rays, %.1f wave iterations per 64 rays, %.1f instructions per ray, active lanes per iteration %.1f of 64, distinct opcodes per iteration %.2f"
               % (scene, name, rays, it * 64.0 / max(1, rays), act / max(1, rays), act / it, nd / it))
