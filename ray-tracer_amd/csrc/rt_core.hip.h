@@ -204,11 +204,13 @@ RT_DEV void hit_add_tex(HitRec &h, int tex) { if (tex >= 0 && h.ntex < RT_MAX_TE
 /* which dynamic limit a ray ran into (Arena::overflow, reported in the error text) */
 enum { OVF_ARENA = 1, OVF_LISTS = 2, OVF_REGIONS = 4, OVF_CAND = 8, OVF_BVH_STACK = 16, OVF_MESH_STACK = 32 };
 /* Where a ray's hit records live.  POOL = false: private (scratch) memory -- lane-interleaved by the hardware, so lanes
-   that use the same index coalesce: right for waves of like rays (every kernel but the one below).  POOL = true: the lane's
-   own RT_ARENA contiguous records of a pool in global memory (RtPipe::arena_pool): right for the scheduled FULL kernels of
-   deep CSG scenes, where a handful of lanes are active at a time -- a 48-byte record of one lane is then one or two 64-byte
-   sectors instead of twelve dwords in twelve different 256-byte rows of the wave's scratch (S4 wrote 17 KB per ray through
-   the fabric that way). */
+   that use the same index coalesce.  Every kernel of the default build.  POOL = true (-DRT_SCHED_POOL, an A/B build): the
+   scheduled FULL kernels keep the records in a pool in global memory (RtPipe::arena_pool), one record per 64-byte sector of the
+   lane's own RT_ARENA sectors; list stacks and the interpreter's arrays stay private (their indices follow the pc, which the
+   lanes of a round share).  Round 2 ran such a pool (with everything in it) under the class scheduler, where seven lanes ran
+   at a time; under the min-pc order (intersect_scene) the private layout is as good: S4 1080p / 4 spp 463 ms private, 455 ms
+   with this pool and its 4.3 GB, and the same 9.5 KB per ray through the fabric either way (tools/pmc_s4_final.sh) -- the
+   records are not what that traffic is made of. */
 template <bool POOL> struct ArenaStore {
     HitRec   h[RT_ARENA];
     uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
@@ -216,23 +218,18 @@ template <bool POOL> struct ArenaStore {
     int32_t  l_gap[RT_LIST_STACK];      /* union regions: LCA depth between this entry and the one below it */
     uint16_t l_idx[RT_LIST_STACK];      /* union regions: last region child merged into this entry */
 };
-/* bytes of a lane's part of the pool: hit records, the list stack, then the interpreter's own arrays (WalkStore) */
-#define RT_POOL_LISTS   (RT_ARENA * 48)
-#define RT_POOL_WALK    (RT_POOL_LISTS + RT_LIST_STACK * 14 + 48)
-#define RT_POOL_STRIDE  ((RT_POOL_WALK + (RT_MAX_AFFINE_DEPTH + 1) * 48 + RT_MAX_REGION_DEPTH * (13 * 4 + RT_MAX_CAND * 2) + 63) / 64 * 64)
+/* a lane's part of the pool: its hit records alone, one per 64-byte sector (a record is 48 bytes: three 16-byte accesses that
+   stay inside one sector, whatever the other lanes' indices are) */
+#define RT_POOL_REC     64
+#define RT_POOL_STRIDE  (RT_ARENA * RT_POOL_REC)
+struct HitPool { char *p; RT_DEV HitRec &operator[](int i) const { return *(HitRec *)(p + (size_t)i * RT_POOL_REC); } };
 template <> struct ArenaStore<true> {
-    HitRec   *h;
-    uint16_t *l_start, *l_count, *l_idx;
-    int32_t  *l_tag, *l_gap;
-    char     *walk;
-    RT_DEV void bind(void *pool, size_t lane)
-    {
-        char *p = (char *)pool + lane * RT_POOL_STRIDE;
-        h = (HitRec *)p;
-        l_tag = (int32_t *)(p + RT_POOL_LISTS); l_gap = l_tag + RT_LIST_STACK;
-        l_start = (uint16_t *)(l_gap + RT_LIST_STACK); l_count = l_start + RT_LIST_STACK; l_idx = l_count + RT_LIST_STACK;
-        walk = p + RT_POOL_WALK;
-    }
+    HitPool  h;
+    uint16_t l_start[RT_LIST_STACK], l_count[RT_LIST_STACK];
+    int32_t  l_tag[RT_LIST_STACK];
+    int32_t  l_gap[RT_LIST_STACK];
+    uint16_t l_idx[RT_LIST_STACK];
+    RT_DEV void bind(void *pool, size_t lane) { h.p = (char *)pool + lane * RT_POOL_STRIDE; }
 };
 template <bool POOL>
 struct ArenaT : ArenaStore<POOL> {
@@ -940,16 +937,8 @@ template <bool POOL> struct WalkStore {
     uint16_t cands[RT_MAX_REGION_DEPTH][RT_MAX_CAND];
     template <class AR> RT_DEV void bind(AR &) {}
 };
-static_assert(sizeof(HitRec) == 48 && sizeof(DRay) == 48 && sizeof(RegionCur) == 52, "RT_POOL_STRIDE is written for these sizes");
-template <> struct WalkStore<true> {
-    DRay *rs; RegionCur *saved; uint16_t (*cands)[RT_MAX_CAND];
-    template <class AR> RT_DEV void bind(AR &A)
-    {
-        rs = (DRay *)A.walk;
-        saved = (RegionCur *)(A.walk + (RT_MAX_AFFINE_DEPTH + 1) * sizeof(DRay));
-        cands = (uint16_t (*)[RT_MAX_CAND])(A.walk + (RT_MAX_AFFINE_DEPTH + 1) * sizeof(DRay) + RT_MAX_REGION_DEPTH * sizeof(RegionCur));
-    }
-};
+static_assert(sizeof(HitRec) == 48, "RT_POOL_REC is written for this size");
+template <> struct WalkStore<true> : WalkStore<false> {};
 
 /* min of lca[a .. b-1], a < b (RtRegion sparse table) */
 RT_DEV int region_gap(const RtDevScene &S, const RegionCur &rg, int a, int b)
