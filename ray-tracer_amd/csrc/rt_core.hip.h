@@ -645,7 +645,7 @@ RT_DEVN void torus_hits(const RtPrim &tp, uint16_t prim, const DRay &ray, AR &A,
 }
 
 /* what a workgroup of a tracing kernel keeps in LDS (scene_lds_load), and where the pre-walked mesh crossings are */
-struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int *mstack; int n_nodes, n_chains, stride;
+struct SceneLds { const double *bvh; const RtChain *chains; uint16_t *stack; int *mstack; int n_nodes, n_chains, stride, groups /* RT_LDS_GROUP_* staged in LDS (scene_lds_load with SL) */;
                   const int *mx_n; const double *mx_t; const int *mx_q; int mxcap; };     /* the pre-walked mesh crossings (RtPipe::mx_*), null = none */
 
 /* ------------------------------------------------------------------ triangle meshes (policy Q14)
@@ -682,6 +682,8 @@ RT_DEV bool mesh_triangle(const RtMeshTri &T, const DRay &ray, double &t)
 }
 #ifdef RT_MESH_COUNT        /* instrumentation build (RT_EXTRA_DEFS=-DRT_MESH_COUNT): [0] rays, [1] node visits, [2] leaf visits, [3] triangle tests, [4] wave-iterations of the node loop, [5] of the leaf loop */
 __device__ unsigned long long g_mesh_count[32];     /* [8..15] FULL, [16..23] LITE interpreter loop: +0 wave iterations, +1 distinct opcodes summed over them, +2 active lanes summed over them, +3 rays, +4 lane iterations */
+/* the loop's counters are kept by one workgroup in 64: same-address atomics of every wave in every round would be what the run measures */
+#define RT_COUNT_SAMPLED ((blockIdx.x & 63) == 0)
 __device__ unsigned long long g_op_time[32], g_op_rounds[32], g_op_lanes[32];      /* SCHED interpreter: per opcode, clock ticks / rounds / lanes of the rounds it led */
 #define MESH_COUNT(k, v) atomicAdd(&g_mesh_count[k], (unsigned long long)(v))
 #define MESH_WAVE_COUNT(k) do { if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_mesh_count[k], 1ull); } while (0)
@@ -988,6 +990,7 @@ RT_DEV SceneLds scene_lds_load(const RtDevScene &S, int n_chains_packed, RtDevSc
     SceneLds L;
     L.mx_n = 0; L.mx_t = 0; L.mx_q = 0; L.mxcap = 0;
     const int groups = (n_chains_packed >> 24) & 3;         /* bit 28 belongs to k_visual (primary level) */
+    L.groups = SL ? groups : 0;
     L.n_nodes = S.n_bvh_lds;
     L.n_chains = n_chains_packed & 0xFFFFFF;
     L.stride = blockDim.x;
@@ -1107,6 +1110,25 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
     }
 }
 
+/* One entry of a small scene table.  in_lds (the same for all lanes): the workgroup staged the table in LDS (scene_lds_load) and
+   the pointer is a generic one into it -- whose low half is the LDS address.  Read through it, the load is an LDS instruction:
+   it counts on the LDS counter alone, where the generic (flat) load the compiler has to emit for a pointer that may be either
+   counts on both and so waits for every store and load to memory still in flight. */
+template <class T> RT_DEV T tab_get(const T *p, const bool in_lds)
+{
+    T v;
+    if (in_lds) __builtin_memcpy(&v, (const __attribute__((address_space(3))) T *)p, sizeof(T));
+    else v = *p;
+    return v;
+}
+/* a pointer every lane holds the same value of, moved to scalar registers */
+template <class T> RT_DEV T *uniform_ptr(T *p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
+
 /* LITE = true compiles the rare, register-hungry features out (torus quartics here; texture call-outs, propagators
    and spectral metals in the kernels): a ray that needs one sets A.bail and is redone by the FULL instantiation.
    The split keeps the common kernels small enough for several waves per SIMD. */
@@ -1117,9 +1139,38 @@ __device__ bool scene_may_hit(const RtDevScene &S, const SceneLds &L, const DRay
    of the level before this kernel) instead of handing the ray over */
 /* SCHED (FULL kernels of long programs, levels behind the first): the lanes of a wave run in the order of their pc -- see the loop */
 template <bool LITE, bool CH_LDS = false, bool TILES = false, bool MESHPRE = false, bool SCHED = false, class AR>
-__device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, AR &A, int &start,
+__device__ int intersect_scene(const RtDevScene &S_in, const SceneLds &L_in, const DRay &wray, double tmax, AR &A, int &start,
                                const unsigned short *tile_list = 0, int tile_n = 0, int tile_one = -1, int mesh_slot = -1)
 {
+    /* In the FULL kernels this is a function of its own, and scene and LDS descriptions arrive by reference: every `S.boxes[..]`
+       would first load the table's pointer from the caller's frame -- a second memory access in front of each table access, whose
+       wait (flat loads count on both counters) also drains every store the round before left in flight.  The pointers are the same
+       for all lanes: they are read once per ray here and kept in scalar registers.  (The LITE kernels inline the function and
+       see the values directly.) */
+    RtDevScene S_uni;
+    SceneLds L_uni;
+    if constexpr (!LITE) {
+        S_uni.prog = uniform_ptr(S_in.prog); S_uni.boxes = uniform_ptr(S_in.boxes); S_uni.affines = uniform_ptr(S_in.affines);
+        S_uni.prims = uniform_ptr(S_in.prims); S_uni.planes = uniform_ptr(S_in.planes); S_uni.mats = uniform_ptr(S_in.mats);
+        S_uni.surfs = uniform_ptr(S_in.surfs); S_uni.clips = uniform_ptr(S_in.clips); S_uni.regions = uniform_ptr(S_in.regions);
+        S_uni.bvh = uniform_ptr(S_in.bvh); S_uni.chains = uniform_ptr(S_in.chains); S_uni.region_child_pc = uniform_ptr(S_in.region_child_pc);
+        S_uni.region_always = uniform_ptr(S_in.region_always); S_uni.region_lca = uniform_ptr(S_in.region_lca);
+        S_uni.region_child_boxes = uniform_ptr(S_in.region_child_boxes); S_uni.root_alt_pc = uniform_ptr(S_in.root_alt_pc);
+        S_uni.n_prog = __builtin_amdgcn_readfirstlane(S_in.n_prog); S_uni.n_root_alt = __builtin_amdgcn_readfirstlane(S_in.n_root_alt);
+        S_uni.root_cull = __builtin_amdgcn_readfirstlane(S_in.root_cull); S_uni.root_cull_arg = __builtin_amdgcn_readfirstlane(S_in.root_cull_arg);
+        S_uni.root_child_pc0 = __builtin_amdgcn_readfirstlane(S_in.root_child_pc0); S_uni.n_bvh_lds = __builtin_amdgcn_readfirstlane(S_in.n_bvh_lds);
+        L_uni.bvh = uniform_ptr(L_in.bvh); L_uni.chains = uniform_ptr(L_in.chains); L_uni.stack = uniform_ptr(L_in.stack); L_uni.mstack = uniform_ptr(L_in.mstack);
+        L_uni.n_nodes = __builtin_amdgcn_readfirstlane(L_in.n_nodes); L_uni.n_chains = __builtin_amdgcn_readfirstlane(L_in.n_chains);
+        L_uni.stride = __builtin_amdgcn_readfirstlane(L_in.stride);
+        L_uni.groups = __builtin_amdgcn_readfirstlane(L_in.groups);
+    }
+    const RtDevScene &S = LITE ? S_in : S_uni;      /* (the mesh walk, a function of its own as well, gets the caller's: S_in, L_in) */
+    const SceneLds &L = LITE ? L_in : L_uni;
+#ifndef RT_TAB_LDS_FULL
+#define RT_TAB_LDS_FULL 0
+#endif
+    const bool tab_lds_on = LITE || RT_TAB_LDS_FULL != 0;
+    const bool ctl_lds = tab_lds_on && (L.groups & RT_LDS_GROUP_CONTROL) != 0, data_lds = tab_lds_on && RT_TAB_LDS_FULL != 2 && (L.groups & RT_LDS_GROUP_DATA) != 0;
     WalkStore<AR::pool> wst;
     wst.bind(A);
     auto &rs = wst.rs; auto &saved = wst.saved; auto &cands = wst.cands;
@@ -1160,22 +1211,22 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         }
     }
 #ifdef RT_MESH_COUNT
-    MESH_COUNT(LITE ? 19 : 11, 1);
+    if (RT_COUNT_SAMPLED) MESH_COUNT(LITE ? 19 : 11, 1);
 #endif
     for (;;) {
 #ifdef RT_MESH_COUNT
         {   /* lanes still in the loop this round, running or waiting for their class: against the lanes that run (+2), the share of
                class serialisation; against 64, the share of rays of unequal length */
             const unsigned long long alive = __ballot(1);
-            if ((__ffsll((long long)alive) - 1) == (int)(threadIdx.x & 63)) { atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 4], (unsigned long long)__popcll(alive)); atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 5], 1ull); }
+            if (RT_COUNT_SAMPLED && (__ffsll((long long)alive) - 1) == (int)(threadIdx.x & 63)) { atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 4], (unsigned long long)__popcll(alive)); atomicAdd(&g_mesh_count[(LITE ? 16 : 8) + 5], 1ull); }
         }
 #endif
-        if (!SCHED || fetch) { in = S.prog[pc]; pc++; }
+        if (!SCHED || fetch) { in = tab_get(S.prog + pc, ctl_lds); pc++; }
 #ifdef RT_MESH_COUNT
         if constexpr (SCHED) {
             if (fetch && cnt_t0) {          /* the round before: charged to the opcode of the first lane that ran in it */
                 const unsigned long long ran = __ballot(1);
-                if ((__ffsll((long long)ran) - 1) == (int)(threadIdx.x & 63)) {
+                if (RT_COUNT_SAMPLED && (__ffsll((long long)ran) - 1) == (int)(threadIdx.x & 63)) {
                     atomicAdd(&g_op_time[cnt_op], (unsigned long long)(clock64() - cnt_t0)); atomicAdd(&g_op_rounds[cnt_op], 1ull); atomicAdd(&g_op_lanes[cnt_op], (unsigned long long)__popcll(ran));
                 }
             }
@@ -1212,7 +1263,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             int nd = 0;
             const int op = in.op;
             while (rest) { const int o = __shfl(op, __ffsll((long long)rest) - 1); rest &= ~__ballot(op == o); nd++; }
-            if ((__ffsll((long long)act) - 1) == (int)(threadIdx.x & 63)) {
+            if (RT_COUNT_SAMPLED && (__ffsll((long long)act) - 1) == (int)(threadIdx.x & 63)) {
                 const int b = LITE ? 16 : 8;
                 atomicAdd(&g_mesh_count[b], 1ull); atomicAdd(&g_mesh_count[b + 1], (unsigned long long)nd); atomicAdd(&g_mesh_count[b + 2], (unsigned long long)__popcll(act));
             }
@@ -1222,13 +1273,13 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         case OP_END:
             goto done;
         case OP_BOUND:
-            if (!cull_box_hit(S.boxes[in.a].lo, S.boxes[in.a].hi, cr)) pc = in.b;
+            { const RtBox bx = tab_get(S.boxes + in.a, data_lds); if (!cull_box_hit(bx.lo, bx.hi, cr)) pc = in.b; }
             break;
         case OP_REFBOX:
-            if (!extent_test(S.boxes[in.a].lo, S.boxes[in.a].hi, cur)) pc = in.b;
+            { const RtBox bx = tab_get(S.boxes + in.a, data_lds); if (!extent_test(bx.lo, bx.hi, cur)) pc = in.b; }
             break;
         case OP_PUSH_AFFINE: {                                  /* AffineSolid::Intersect, Solids.cpp:899-913 */
-            const RtAffine &a = S.affines[in.a];
+            const RtAffine a = tab_get(S.affines + in.a, data_lds);
             DRay nr;
             nr.dir = mat_vec(a.minv, cur.dir);
             nr.org = mat_vec(a.minv, cur.org - d3(a.tr[0], a.tr[1], a.tr[2]));
@@ -1250,7 +1301,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
         case OP_MESH:
             if constexpr (LITE && !MESHPRE) { A.bail = 1; goto done; }
             else if constexpr (LITE) { mesh_hits<false>(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); if (A.bail) goto done; break; }
-            else { PROF_BEGIN(tp); mesh_hits<true>(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); mesh_hits<true>(S_in, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L_in); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -1304,7 +1355,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             if (!top_is(A, 2 * in.a)) pc = in.b;
             break;
         case OP_REGION: {
-            const RtRegion rg = S.regions[in.a];
+            const RtRegion rg = tab_get(S.regions + in.a, ctl_lds);
             if (nrf >= RT_MAX_REGION_DEPTH) { A.overflow |= OVF_REGIONS; pc = rg.end_pc; break; }
             uint16_t *cd = cands[nrf];
             int ov = 0;
@@ -1329,7 +1380,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             cf.child_pc0 = rg.child_pc0; cf.lca0 = rg.lca0; cf.nchild = rg.n_children; cf.uid = rg.uid; cf.end_pc = rg.end_pc;
             cf.cur_c = cd[0]; cf.top_idx = 0; cf.top_gap = -1;
             nrf++;
-            pc = S.region_child_pc[cf.child_pc0 + cf.cur_c];
+            pc = tab_get(S.region_child_pc + (cf.child_pc0 + cf.cur_c), ctl_lds);
             break;
         }
         case OP_CHAIN: {
@@ -1337,7 +1388,10 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
             /* CH_LDS: every chain record of the scene is staged in LDS (decided per launch, so that the loads below
                are LDS loads and not generic ones) */
             const RtChain &ch = CH_LDS ? L.chains[in.a] : S.chains[in.a];
-            if ((ch.test_box & RT_CHAIN_TEST_BOX) && !cull_box_hit(S.boxes[ch.box].lo, S.boxes[ch.box].hi, cr)) { if (in.b & 1) goto region_ret; break; }
+            if (ch.test_box & RT_CHAIN_TEST_BOX) {
+                const RtBox bx = tab_get(S.boxes + ch.box, data_lds);
+                if (!cull_box_hit(bx.lo, bx.hi, cr)) { if (in.b & 1) goto region_ret; break; }
+            }
             DRay r = cur;
             if (ch.n_affine) {                                      /* AffineSolid::Intersect, Solids.cpp:899-913 */
                 DRay nr;
@@ -1366,7 +1420,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
                         break;
                     } else {
-                        if (ch.prim_op == OP_MESH) mesh_hits<true>(S, pr, (uint16_t)ch.prim, r, A, in.tag, L);
+                        if (ch.prim_op == OP_MESH) mesh_hits<true>(S_in, pr, (uint16_t)ch.prim, r, A, in.tag, L_in);
                         else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
@@ -1400,7 +1454,7 @@ __device__ int intersect_scene(const RtDevScene &S, const SceneLds &L, const DRa
                 }
                 cf.nl_before = A.nlist;
                 cf.cur_c = next;
-                pc = S.region_child_pc[cf.child_pc0 + next];
+                pc = tab_get(S.region_child_pc + (cf.child_pc0 + next), ctl_lds);
             } else {
                 while (A.nlist - cf.base_lists >= 2) merge_top(A, MERGE_MAX, S.mats, ctag);
                 if (A.nlist - cf.base_lists == 1) list_retag_top(A, cf.out_tag);
@@ -1977,8 +2031,10 @@ __device__ DRay ray_in_frame(const RtDevScene &S, const DRay &wray, int k)
 
 /* TransformNormals, Shade.cpp:264-284.  LITE: a hit with queued texture call-outs sets bail instead. */
 /* own_minv (LITE callers that hold the hit's chain record, RT_CHAIN_OWN_NORMAL): the whole transform is that one matrix */
+/* (inlined: as a function of its own the compiler parks two values in accumulation registers, and every FULL kernel that calls it
+   then needs 258 registers -- one wave per SIMD instead of the two its launch bounds ask for; S4's k_shadow ran that way) */
 template <bool LITE>
-__device__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail, const double *own_minv = 0)
+__device__ __forceinline__ void transform_normals(const RtDevScene &S, const DRay &wray, const HitRec &hr, ShadeHit &h, const double *aux, bool &bail, const double *own_minv = 0)
 {
     h.t = hr.t; h.n = hr.n; h.np = d3(0, 0, 0); h.perturbed = 0; h.surf = hr.surf; h.mat = hr.mat; h.has_color = 0; h.luster_ov = -1; h.rough_ov = -1;
     if constexpr (LITE) {
