@@ -187,10 +187,10 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    features; at rt_scene_upload; results do not depend on it),
    "direct_full" (0/1, default 1: a recursion level of a chunk whose rays the common kernels mostly handed over the last time the
    same chunk was rendered goes to the kernels for the rare features at once; results do not depend on it),
-   "sched" (0/1/2, default 2 = for programs of 256 instructions and more: behind the first recursion level those kernels run one class of opcodes per round of
-   the interpreter and keep their per-ray hit records in a pool in global memory, contiguous per lane, instead of private
-   memory -- 3.45 GB on an MI355X (RT_POOL_STRIDE = 26,304 B x 131,072 lanes: 512 hit records of 48 B, the list stack and the
-   interpreter's arrays per lane), part of the queue pool; the kernels for the rare features also reserve 24 KB of private memory per lane; at rt_scene_upload; results do not depend on it),
+   "sched" (0/1/2, default 2 = for programs of 256 instructions and more: behind the first recursion level those kernels run, in
+   every round of the interpreter, the lanes of a wave that sit at the smallest program counter -- every jump of a program goes
+   forward, so the lanes ahead wait for the others to catch up and the lanes of a round execute one and the same instruction;
+   the kernels for the rare features reserve 29 KB of private memory per lane; at rt_scene_upload; results do not depend on it),
    "sort_rays" (0/1, default 1: the levels behind the first that go to the kernels for the rare features directly are traced in the order of a key --
    direction octant and dominant axis, then the Morton cell of the origin -- sorted on the device; results do not depend on it),
    "direct_pct_deep" (default 40: the share of a level's rays the common kernels must have handed over for a sorted level to go
