@@ -191,6 +191,9 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    every round of the interpreter, the lanes of a wave that sit at the smallest program counter -- every jump of a program goes
    forward, so the lanes ahead wait for the others to catch up and the lanes of a round execute one and the same instruction;
    the kernels for the rare features reserve 29 KB of private memory per lane; at rt_scene_upload; results do not depend on it),
+   "expect_empty" (0/1, default 1: a scene whose first level was empty in the call before -- every primary ray ended in the
+   generator or in the fast path -- has that level shaded by a few looping workgroups and traced by a small launch instead of
+   launches sized for the upper bound, which is all the host knows; results do not depend on it, nor on the expectation being right),
    "sort_rays" (0/1, default 1: the levels behind the first that go to the kernels for the rare features directly are traced in the order of a key --
    direction octant and dominant axis, then the Morton cell of the origin -- sorted on the device; results do not depend on it),
    "direct_pct_deep" (default 40: the share of a level's rays the common kernels must have handed over for a sorted level to go

@@ -576,6 +576,7 @@ __global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
         if (level0) {           /* measurement: how the call's primary rays were traced (the line outlives the pass) */
             P.counters[CTR_OVERFLOW + 2] += P.counters[CTR_FAST];
             P.counters[CTR_OVERFLOW + 3] += (gen_frames < 0 ? nf : gen_frames) - P.counters[CTR_FAST + 1];     /* level-0 frames k_visual traced: all but k_fast's own */
+            if (nf > 0) P.counters[CTR_OVERFLOW + 4] = 1;      /* level 0 had frames at all (the next call's expectation: k_shade_loop) */
         }
     }
 }
@@ -1912,13 +1913,9 @@ RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags
  * behind the tracing kernels) and the host has launched for an upper bound -- workgroups beyond the end leave at once.
  * (A grid-stride loop over the frames made the compiler hoist per-frame address arithmetic out of it and spill 308 B per
  * lane at three waves per SIMD: 2.3 x slower per frame.) */
-__global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+RT_DEV void shade_frames(const RtDevScene &S, const RtPipe &P, const int fb, const int f1, float *out_rgb, float *out_spec)
 {
-    const RtDevScene &S = Sv;
-    if (f1 < 0) f1 = P.counters[CTR_SNAP];
   {
-    const int fb = f0 + blockIdx.x * 256;
-    if (fb >= f1) return;
     const int f = fb + threadIdx.x;
     const bool live = f < f1;
     int nchild = 0, flags = 0;
@@ -1994,6 +1991,22 @@ __global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P,
         P.f_flags[nf] = FR_MAKE_DEPTH(depth + 1) | (which ? FR_SLOT2 : 0);
     }
   }
+}
+__global__ void __launch_bounds__(256, 3) k_shade(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)
+{
+    if (f1 < 0) f1 = P.counters[CTR_SNAP];
+    const int fb = f0 + blockIdx.x * 256;
+    if (fb >= f1) return;
+    shade_frames(Sv, P, fb, f1, out_rgb, out_spec);
+}
+/* The same over a level whose end is on the device and is EXPECTED to be at f0 (the call before on this scene left level 0 empty:
+   S0, whose primary rays all end in the generator or in k_fast): a few workgroups that loop, instead of one workgroup per 256
+   frames of the upper bound -- 518 k workgroups that read the counter and leave cost 0.11 ms per pass, 4 % of a band of an
+   eight-way split.  If the expectation is wrong the loop does the work, correctly and some 2 x slower per frame (see above). */
+__global__ void __launch_bounds__(256, 3) k_shade_loop(const RtDevScene Sv, RtPipe P, int f0, float *out_rgb, float *out_spec)
+{
+    const int f1 = P.counters[CTR_SNAP];
+    for (int fb = f0 + blockIdx.x * 256; fb < f1; fb += gridDim.x * 256) shade_frames(Sv, P, fb, f1, out_rgb, out_spec);
 }
 
 /* ------------------------------------------------------------------ k_resolve */

@@ -1005,6 +1005,37 @@ def test_wrapper_push_down_is_invisible(gpu, oracle, scene):
 SCENE_POLISHED_ROW = SCENE_ROW.replace("plastic none none (sphere)", "plastic none none (surface polished none (sphere))")
 
 
+
+def test_expected_empty_level0_is_invisible(gpu):
+    """Option expect_empty: a scene whose level 0 was empty in the call before (S0: every primary ray ends in the generator or in
+    k_fast) has that level shaded by a few looping workgroups (k_shade_loop) and traced by a small launch instead of launches sized
+    for the upper bound.  The expectation is only about launch shapes: frames equal the ones rendered with the option off -- when
+    it holds (second and third render of S0), and when it does not (the fast path off, so that every surviving primary ray is a
+    frame: first a row of sky, which leaves level 0 empty, then a whole frame under the expectation that it is empty)."""
+    fs = gpu.FrontScene("S0", "fastblue", optimize=True)
+    try:
+        gpu.set_options({"expect_empty": 0})
+        g0 = gpu.GpuScene(fs.desc)
+        ref, sr = g0.render(480, 270, 16)
+        gpu.set_options({"expect_empty": 1})
+        g1 = gpu.GpuScene(fs.desc)
+        for k in range(3):
+            a, sa = g1.render(480, 270, 16)
+            assert np.array_equal(a, ref) and sa.rays() == sr.rays() and sa.rays_fast == sr.rays_fast, k
+        band, _ = g1.render(480, 270, 16, row0=100, row1=171)
+        assert np.array_equal(band[:, 100:171, :], ref[:, 100:171, :])
+        gpu.set_options({"fast_path": 0})
+        g2 = gpu.GpuScene(fs.desc)
+        sky, ss = g2.render(270, 480, 16, row0=0, row1=1)
+        assert ss.rays_visual0 == 0 and sky.max() == 0.0          # nothing but sky at the top of an upright frame: level 0 stays empty
+        b, sb = g2.render(480, 270, 16)                               # ... and now it does not
+        assert sb.rays_visual0 > 0 and sb.rays_fast == 0
+        assert np.array_equal(b, ref) and sb.rays() == sr.rays()
+        c, sc = g2.render(480, 270, 16)                               # (the expectation is gone again)
+        assert np.array_equal(c, ref) and sc.rays_visual0 == sb.rays_visual0
+    finally:
+        gpu.set_options({"fast_path": 1, "expect_empty": 1})
+
 @pytest.mark.parametrize("scene", ["S0", SCENE_ROW, SCENE_POLISHED_ROW, SCENE_FOG_PERSPECTIVE], ids=["S0_inline", "row_shadow_frames", "row_polished_children", "fog_not_eligible"])
 def test_fast_path_is_invisible(gpu, scene):
     """k_fast (primary rays that can touch ONE bare chain of the root region: no interpreter, no hit arena, hits in
