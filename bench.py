@@ -175,6 +175,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    if rehearse and world > 2:
+        # the ranks share ONE device's memory here, and each sizes its queue pool from what is free: smaller passes, so that all fit
+        rt.rt_lib().rt_set_option(b"chunk_samples", max(1 << 20, (1 << 25) // world))
     for kv in filter(None, args.opts.split(",")):
         name, val = kv.split("=")
         if rt.rt_lib().rt_set_option(name.encode(), int(val)):
