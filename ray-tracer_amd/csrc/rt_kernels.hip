@@ -418,9 +418,17 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
 {
     const RtDevScene &S = Sv;
     __shared__ int wave_count[2][RT_GEN_ITERS][4], wave_base[2][RT_GEN_ITERS][4], block_base[2];
+    const int k0 = blockIdx.x * RT_GEN_SPAN;
+    if (g.tile_mask && g.mask_skips_rgb && !rays_org && k0 < n) {
+        /* the workgroup's samples belong to one or two sampling tiles (1536 consecutive samples, tiles of 1600): when no ray through
+           either can touch the scene there is nothing to do here at all -- not even the staging below.  Half of S0's samples. */
+        int i_;
+        const int k1 = (k0 + RT_GEN_SPAN < n ? k0 + RT_GEN_SPAN : n) - 1;
+        const uint32_t ta = tile_of(first, k0, i_), tb = tile_of(first, k1, i_);
+        if (g.tile_mask[ta] == 0 && g.tile_mask[tb] == 0) return;
+    }
     const SceneLds lds = scene_lds_load(S, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * RT_GEN_SPAN;
     const bool fast_on = S.root_fast && P.tile_cand && !rays_org;       /* the host runs k_fast and the tile-list build of k_visual together */
     unsigned keep_bits = 0, fast_bits = 0;
     unsigned long long prefix = 0, prefix_f = 0;    /* 7 bits per iteration: survivors of that kind before this lane in its wave */
@@ -2642,14 +2650,14 @@ RT_DEV void splat_pixel_lds(const RtSampleGrid &g, const SplatRowLds &L, const f
                 const RtSplatEntry en = L.ent[e];
                 /* v = g_rgvBlueNoise[i]*BLUE_NSQRT + vTile (Sampling.cpp:501), then FastSplatRGB's own arithmetic: as splat_pixel */
                 double x = en.bx + (double)tx * (double)RT_BLUE_NSQRT;
-                double y = en.by + (double)ty * (double)RT_BLUE_NSQRT;
-                x -= 0.5; y -= 0.5;
-                const double fx = floor(x), fy = floor(y);
-                const int i1 = (int)fx, j1 = (int)fy;
-                const double dx = x - fx, dy = y - fy;
-                double wx, wy;
+                x -= 0.5;
+                const double fx = floor(x);
+                const int i1 = (int)fx;
+                const double dx = x - fx;
+                double wx;
                 if (px == i1) wx = 1.0 - dx; else if (px == i1 + 1) wx = dx; else continue;
-                if (py == j1) wy = 1.0 - dy; else if (py == j1 + 1) wy = dy; else continue;
+                const double wy = en.by;            /* the row's weight: the same for every tile of the span, formed once when the row was staged */
+                if (wy < 0.0) continue;
                 w += (float)(wx * wy);
                 if (black) continue;
                 const float *c = sample_rgb + 3 * (sbase + en.i);
@@ -2714,7 +2722,20 @@ __global__ void __launch_bounds__(256) k_splat_rows_need(RtSampleGrid g, RtSplat
             const int c0 = ((q ? L.cy1 : ly) + 1) * (RT_BLUE_NSQRT + 2);        /* first cell of the row: (cy + 1) * 42 + (cx + 1), cx = -1 */
             const int eb = ST.offsets[c0], ee = ST.offsets[c0 + RT_BLUE_NSQRT + 2];
             for (int k = threadIdx.x; k <= RT_BLUE_NSQRT + 2; k += 256) s_off[q * RT_FS_OFFS + k] = ST.offsets[c0 + k] - eb + at;
-            for (int k = threadIdx.x; k < ee - eb; k += 256) s_ent[at + k] = ST.entries_pos[eb + k];
+            /* ... with `by` replaced by the sample's weight for THIS row (-1: it does not reach the row): the tile row the cell row belongs
+               to is the same for every tile of the span, so FastSplatRGB's arithmetic on y (Sampling.cpp:501 and the splat's own, as
+               splat_pixel does it) is done once per entry here instead of once per entry and pixel */
+            const int ty_q = (py - (q ? L.cy1 : ly)) / RT_BLUE_NSQRT;
+            for (int k = threadIdx.x; k < ee - eb; k += 256) {
+                RtSplatEntry en = ST.entries_pos[eb + k];
+                double y = en.by + (double)ty_q * (double)RT_BLUE_NSQRT;
+                y -= 0.5;
+                const double fy = floor(y);
+                const int j1 = (int)fy;
+                const double dy = y - fy;
+                en.by = py == j1 ? 1.0 - dy : (py == j1 + 1 ? dy : -1.0);
+                s_ent[at + k] = en;
+            }
             at += ee - eb;
         }
     }
