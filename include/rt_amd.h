@@ -191,6 +191,9 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    every round of the interpreter, the lanes of a wave that sit at the smallest program counter -- every jump of a program goes
    forward, so the lanes ahead wait for the others to catch up and the lanes of a round execute one and the same instruction;
    the kernels for the rare features reserve 29 KB of private memory per lane; at rt_scene_upload; results do not depend on it),
+   "rgb_sorted" (0/1, default 1: render calls whose reconstruction is the fused gather + row filter keep the colours of a sampling
+   tile's 1600 samples in the order (supersample row, x) instead of sample order, so that what a row of the reconstruction gathers
+   from a tile lies together in memory; rt_trace_samples always hands out sample order; results do not depend on it),
    "expect_empty" (0/1, default 1: a scene whose first level was empty in the call before -- every primary ray ended in the
    generator or in the fast path -- has that level shaded by a few looping workgroups and traced by a small launch instead of
    launches sized for the upper bound, which is all the host knows; results do not depend on it, nor on the expectation being right),

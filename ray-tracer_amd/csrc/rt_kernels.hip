@@ -380,6 +380,13 @@ RT_DEV void root_frame(const RtDevScene &S, const RtPipe &P, int f, int k, const
     P.f_flags[f] = (int)((unsigned)hint << FR_HINT_SHIFT);
 }
 
+/* sample k of a chunk (chunks start on tile boundaries) -> its place in the sample buffer (RtSampleGrid::rgb_slot) */
+RT_DEV int rgb_slot_of(const unsigned short *slot, const int k)
+{
+    if (!slot) return k;
+    const int i = k % RT_BLUE_N;
+    return k - i + (int)slot[i];
+}
 /* work item k of a chunk -> the sample it traces (RtSampleGrid::fb_order) */
 RT_DEV int trace_order(const RtSampleGrid &g, int64_t first, int k)
 {
@@ -519,7 +526,7 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
                 }
             }
             if (!keep && !fast && !(masked && g.mask_skips_rgb)) {
-                if (out_rgb) { out_rgb[(size_t)k * 3] = 0.0f; out_rgb[(size_t)k * 3 + 1] = 0.0f; out_rgb[(size_t)k * 3 + 2] = 0.0f; }
+                if (out_rgb) { const size_t ks = (size_t)rgb_slot_of(rays_org ? 0 : g.rgb_slot, k); out_rgb[ks * 3] = 0.0f; out_rgb[ks * 3 + 1] = 0.0f; out_rgb[ks * 3 + 2] = 0.0f; }
                 if (out_spec) for (int i = 0; i < RT_NSPEC; i++) out_spec[(size_t)k * RT_NSPEC + i] = 0.0f;
             }
         }
@@ -1166,7 +1173,7 @@ RT_DEV Spec light_loop(const RtDevScene &S, const D3 &Ppt, const D3 &cvN, const 
     }
     return R;
 }
-RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec);
+RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec, const unsigned short *slot);
 
 /* 512 threads = two waves per SIMD and 256 registers: measured on S0 4K / 64 spp, 512 / 768 / 1024 threads = 0.54 / 0.59 / 0.69 ms
    per launch of 5.4 M rays -- what the narrower builds spill (480 B and 700 B per lane) costs more than the waves they add */
@@ -1297,7 +1304,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FAST_THREADS, 1) k
             Spec R = B.R;
             if (B.flags & FR_BOUNDARY)
                 R = light_loop(S, B.P, K.N, K.E, K.HN, K.F, K.rough, K.luster, K.color, R, aux[2], aux[3], 0u, [](int, Spec &) { return false; });
-            sample_deliver(S, k, R, out_rgb, out_spec);
+            sample_deliver(S, k, R, out_rgb, out_spec, g.rgb_slot);
         }
     }
     /* the lanes that could not finish become level-0 frames behind the generator's: traced ones (FR_TRACED: the record
@@ -1479,7 +1486,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTA_THREADS, 1) 
         }
         if (hand_over) boundary = false;
         else if (bail) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], OVF_FAST_BAIL); boundary = false; }
-        else if (!boundary) sample_deliver(S, k, final ? spec_load(S.mats[pm].color) : spec_const(0.0f), out_rgb, out_spec);
+        else if (!boundary) sample_deliver(S, k, final ? spec_load(S.mats[pm].color) : spec_const(0.0f), out_rgb, out_spec, g.rgb_slot);
     }
     /* the record sits at the queue entry's own index (-1 = none): compacting the records would cost one same-address atomic per
        64 rays -- measured: 560 k of them per launch made this kernel 1.6 x slower than all of k_fast -- and buys k_fast_shade the
@@ -1582,7 +1589,7 @@ __global__ void __attribute__((flatten)) __launch_bounds__(RT_FASTB_THREADS, 1) 
         } else if (B.n_shadow > 0 || K.rough == RT_SURF_POLISHED) { need_frame = true; n_shadow = B.n_shadow; }
         else {
             const Spec R = light_loop(S, B.P, K.N, K.E, K.HN, K.F, K.rough, K.luster, K.color, B.R, aux[2], aux[3], 0u, [](int, Spec &) { return false; });
-            sample_deliver(S, k, R, out_rgb, out_spec);
+            sample_deliver(S, k, R, out_rgb, out_spec, g.rgb_slot);
         }
     }
     /* The lanes that need shadow rays or children become traced level-0 frames (FR_TRACED) for k_shade, as in k_fast.  They walk
@@ -2019,7 +2026,7 @@ __global__ void __launch_bounds__(256, 3) k_shade_loop(const RtDevScene Sv, RtPi
 
 /* ------------------------------------------------------------------ k_resolve */
 /* a root's finished radiance to its sample: Spectrum::sRGB / vRGB (RadiometryColor.h:62-66, RadiometryColor.cpp:971-983) */
-RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec)
+RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, float *out_rgb, float *out_spec, const unsigned short *slot)
 {
     if (out_spec) for (int k = 0; k < RT_NSPEC; k++) out_spec[(size_t)root * RT_NSPEC + k] = R.v[k];
     if (out_rgb) {
@@ -2034,7 +2041,8 @@ RT_DEV void sample_deliver(const RtDevScene &S, const int root, const Spec &R, f
                 b = b + (float)((double)S.spec2rgb[i][2] * w);
             }
         }
-        out_rgb[(size_t)root * 3] = r; out_rgb[(size_t)root * 3 + 1] = g; out_rgb[(size_t)root * 3 + 2] = b;
+        const size_t rs = (size_t)rgb_slot_of(slot, root);
+        out_rgb[rs * 3] = r; out_rgb[rs * 3 + 1] = g; out_rgb[rs * 3 + 2] = b;
     }
 }
 /* hand a frame's finished radiance to its parent (Shade.cpp:491-501) or, for a root, to the sample */
@@ -2045,7 +2053,7 @@ RT_DEV void frame_deliver(const RtDevScene &S, const RtPipe &P, int f, int flags
         spec_store((flags & FR_SLOT2) ? P.f_c2 : P.f_c1, P.fcap, parent, R);
         return;
     }
-    sample_deliver(S, P.f_root[f], R, out_rgb, out_spec);
+    sample_deliver(S, P.f_root[f], R, out_rgb, out_spec, P.rgb_slot);
 }
 
 __global__ void __launch_bounds__(256) k_resolve(const RtDevScene Sv, RtPipe P, int f0, int f1, float *out_rgb, float *out_spec)

@@ -91,6 +91,7 @@ typedef struct RtPipe {
     /* hit records of the scheduled FULL kernels (ArenaT<true>, rt_core.hip.h): RT_ARENA contiguous 48-byte records per lane of the
        largest such launch (n_cu x RT_FULL_PER_CU x 256 lanes); null = those kernels are not used */
     void                 *arena_pool;
+    const unsigned short *rgb_slot;     /* RtSampleGrid::rgb_slot of the chunk being traced (for the kernels that only get the pipe) */
     /* ray order for those kernels (k_sort_keys, rt_kernels.hip): keys in and out (2 x sort_cap), identity values (sort_cap), the
        origins' box (8 ints) and the radix sort's scratch; null = levels are traced in queue order */
     unsigned             *sort_keys;
@@ -134,6 +135,11 @@ typedef struct RtSampleGrid {   /* geometry of one render call's sample set */
        instead of from all over the tile.  Which sample a work item is changes, nothing else does: results are stored
        by sample index.  Null = trace in index order (chunks that do not start and end on tile boundaries). */
     const unsigned short *fb_order;
+    /* FASTBLUE render calls whose reconstruction is k_splat_rows_need: where sample i of a tile keeps its colour in the tile's 1600
+       slots of the sample buffer -- the samples sorted by the supersample row they fall into, then by x, so that what a row of the
+       reconstruction gathers from a tile lies in two short runs instead of all over the tile's 19 KB.  Null = slot i (every other
+       caller: the sample buffer is then in sample order, which is what rt_trace_samples hands out).  Needs fb_order (tile-aligned chunks). */
+    const unsigned short *rgb_slot;
     int     need_lazy;                  /* the passes behind the splat gather take the pixels of tiles with tile_need == 0 as zeros without reading
                                            them (RtNeedMap::lazy): the gather does not write them */
     int     mask_skips_rgb;             /* the caller's reconstruction honours the mask: masked tiles' (black) sample colours are neither written nor read */

@@ -1006,6 +1006,26 @@ SCENE_POLISHED_ROW = SCENE_ROW.replace("plastic none none (sphere)", "plastic no
 
 
 
+def test_sorted_sample_buffer_is_invisible(gpu):
+    """Option rgb_sorted: render calls whose reconstruction is the fused gather + row filter keep a tile's sample colours in the
+    order (supersample row, x) instead of sample order, so that what a row gathers from a tile lies together.  Every writer (the
+    generator's zeros, the fast path, k_shade / k_resolve) and the one reader use the same slots: frames, bands and ray counts
+    equal the ones with the option off -- S0 (fast path, masked tiles), S1 (interpreter, shadows, reflections), a glass scene."""
+    try:
+        for scene, sizes in (("S0", ((480, 270, 16, 0, 0), (333, 187, 9, 40, 101), (64, 64, 1, 0, 0))),
+                             ("S1", ((320, 180, 16, 0, 0), (200, 120, 4, 17, 63))), ("S4", ((240, 135, 4, 0, 0),))):
+            fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+            g = gpu.GpuScene(fs.desc)
+            for (w, h, spp, r0, r1) in sizes:
+                gpu.set_options({"rgb_sorted": 0})
+                a, sa = g.render(w, h, spp, row0=r0, row1=r1)
+                gpu.set_options({"rgb_sorted": 1})
+                b, sb = g.render(w, h, spp, row0=r0, row1=r1)
+                assert np.array_equal(a, b) and sa.rays() == sb.rays() and a.max() > 0, (scene, w, h, spp)
+    finally:
+        gpu.set_options({"rgb_sorted": 1})
+
+
 def test_expected_empty_level0_is_invisible(gpu):
     """Option expect_empty: a scene whose level 0 was empty in the call before (S0: every primary ray ends in the generator or in
     k_fast) has that level shaded by a few looping workgroups (k_shade_loop) and traced by a small launch instead of launches sized
