@@ -449,7 +449,9 @@ __global__ void __launch_bounds__(256) k_generate_cull(const RtDevScene Sv, RtSa
             k = trace_order(g, first, k);
             /* a wave's 64 samples belong to one tile (1600 = 25 x 64, chunks start at multiples of 64): uniform branch */
             int ti_;
-            const uint32_t tile = tile_of(first, k, ti_);
+            /* ... and says so to the compiler: the tile's mask, its list and the listed boxes are then scalar loads and scalar loop
+               control instead of 64 identical vector loads each */
+            const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_of(first, k, ti_));
             const int tm = (g.tile_mask && !rays_org) ? (int)g.tile_mask[tile] : 255;
             const bool masked = tm == 0;
             if (!masked) {
