@@ -245,6 +245,40 @@ struct ArenaT : ArenaStore<POOL> {
 #endif
 };
 typedef ArenaT<false> Arena;
+/* The FULL kernels' interpreter is a function of its own and gets the arena by reference: its counters (nlist, top, the mirror of
+   the top list entry ...) then live in the caller's frame, every look at them is a load from memory behind whatever stores are in
+   flight, and every 48-byte record copy -- which the compiler has to assume may overlap them -- makes it read them again.  The
+   function therefore works on a VIEW: the arrays through pointers, the counters by value in a local object whose address never
+   leaves the function (intersect_scene_full inlines all users), so they are registers; the two rare callees that are functions of
+   their own (torus, mesh walk) get the caller's arena, brought up to date around the call (arena_call_out). */
+struct ArenaView {
+    static constexpr bool pool = false;
+    HitRec   *h;
+    uint16_t *l_start, *l_count, *l_idx;
+    int32_t  *l_tag, *l_gap;
+    ArenaT<false> *home;
+    int      nlist, t_start, t_count, t_tag, top, overflow, bail, mesh_slot;
+#ifdef RT_PHASE_PROF
+    int      prof[12];
+#endif
+    RT_DEV void load(ArenaT<false> &a)
+    {
+        nlist = a.nlist; t_start = a.t_start; t_count = a.t_count; t_tag = a.t_tag; top = a.top; overflow = a.overflow; bail = a.bail; mesh_slot = a.mesh_slot;
+#ifdef RT_PHASE_PROF
+        for (int q = 0; q < 12; q++) prof[q] = a.prof[q];
+#endif
+    }
+    RT_DEV void commit() const
+    {
+        ArenaT<false> &a = *home;
+        a.nlist = nlist; a.t_start = t_start; a.t_count = t_count; a.t_tag = t_tag; a.top = top; a.overflow = overflow; a.bail = bail; a.mesh_slot = mesh_slot;
+#ifdef RT_PHASE_PROF
+        for (int q = 0; q < 12; q++) a.prof[q] = prof[q];
+#endif
+    }
+};
+template <class F> RT_DEV void arena_call_out(ArenaT<false> &A, F f) { f(A); }
+template <class F> RT_DEV void arena_call_out(ArenaView &A, F f) { A.commit(); f(*A.home); A.load(*A.home); }
 #ifdef RT_PHASE_PROF
 #define PROF_BEGIN(v)      long long v = clock64()
 #define PROF_END(A, k, v)  (A).prof[k] += (int)(clock64() - v)
@@ -1323,11 +1357,11 @@ __device__ int intersect_scene(const RtDevScene &S_in, const SceneLds &L_in, con
         case OP_SLAB:    { PROF_BEGIN(tp); slab_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
         case OP_TORUS:
             if constexpr (LITE) { A.bail = 1; goto done; }
-            else { PROF_BEGIN(tp); torus_hits(S.prims[in.a], (uint16_t)in.a, cur, A, in.tag); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); arena_call_out(A, [&](ArenaT<false> &X) { torus_hits(S.prims[in.a], (uint16_t)in.a, cur, X, in.tag); }); PROF_END(A, 2, tp); break; }
         case OP_MESH:
             if constexpr (LITE && !MESHPRE) { A.bail = 1; goto done; }
             else if constexpr (LITE) { mesh_hits<false>(S, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L); if (A.bail) goto done; break; }
-            else { PROF_BEGIN(tp); mesh_hits<true>(S_in, S.prims[in.a], (uint16_t)in.a, cur, A, in.tag, L_in); PROF_END(A, 2, tp); break; }
+            else { PROF_BEGIN(tp); arena_call_out(A, [&](ArenaT<false> &X) { mesh_hits<true>(S_in, S.prims[in.a], (uint16_t)in.a, cur, X, in.tag, L_in); }); PROF_END(A, 2, tp); break; }
         case OP_MATERIAL: {                                     /* Material::Intersect, Solids.cpp:1466-1487 */
             if (!top_is(A, 2 * in.b)) break;
             int s = A.t_start, c = A.t_count;
@@ -1446,8 +1480,8 @@ __device__ int intersect_scene(const RtDevScene &S_in, const SceneLds &L_in, con
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
                         break;
                     } else {
-                        if (ch.prim_op == OP_MESH) mesh_hits<true>(S_in, pr, (uint16_t)ch.prim, r, A, in.tag, L_in);
-                        else torus_hits(pr, (uint16_t)ch.prim, r, A, in.tag);
+                        if (ch.prim_op == OP_MESH) arena_call_out(A, [&](ArenaT<false> &X) { mesh_hits<true>(S_in, pr, (uint16_t)ch.prim, r, X, in.tag, L_in); });
+                        else arena_call_out(A, [&](ArenaT<false> &X) { torus_hits(pr, (uint16_t)ch.prim, r, X, in.tag); });
                         if (A.nlist > before)
                             for (int i = 0; i < A.t_count; i++) { HitRec h = A.h[A.t_start + i]; hit_apply_wraps(ch, h); A.h[A.t_start + i] = h; }
                         break;
@@ -1520,6 +1554,34 @@ done:
     if (A.nlist > 0 && A.t_tag == 0) { start = A.t_start; return A.t_count; }
     start = 0;
     return 0;
+}
+
+/* the FULL kernels' entry: a function of its own (inlined into those kernels it costs the second wave per SIMD) that runs the
+   interpreter, with everything it calls but the torus and the mesh walk inlined, on a view of the caller's arena (ArenaView) */
+template <bool CH_LDS, bool TILES, bool SCHED>
+__device__ __noinline__ __attribute__((flatten)) int intersect_scene_full(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, ArenaT<false> &A, int &start,
+                                                                          const unsigned short *tile_list, int tile_n, int tile_one, int mesh_slot)
+{
+    ArenaView V;
+    V.h = uniform_ptr(&A.h[0]);
+    V.l_start = uniform_ptr(&A.l_start[0]); V.l_count = uniform_ptr(&A.l_count[0]); V.l_idx = uniform_ptr(&A.l_idx[0]);
+    V.l_tag = uniform_ptr(&A.l_tag[0]); V.l_gap = uniform_ptr(&A.l_gap[0]);
+    V.home = uniform_ptr(&A);
+    int st = 0;
+    const int count = intersect_scene<false, CH_LDS, TILES, false, SCHED>(S, L, wray, tmax, V, st, tile_list, tile_n, tile_one, mesh_slot);
+    V.commit();
+    start = st;
+    return count;
+}
+template <bool LITE, bool CH_LDS, bool TILES, bool MESHPRE, bool SCHED, class AR>
+RT_DEV int trace_scene(const RtDevScene &S, const SceneLds &L, const DRay &wray, double tmax, AR &A, int &start,
+                       const unsigned short *tile_list, int tile_n, int tile_one, int mesh_slot)
+{
+#ifndef RT_SCHED_POOL
+    if constexpr (!LITE) return intersect_scene_full<CH_LDS, TILES, SCHED>(S, L, wray, tmax, A, start, tile_list, tile_n, tile_one, mesh_slot);
+    else
+#endif
+    return intersect_scene<LITE, CH_LDS, TILES, MESHPRE, SCHED>(S, L, wray, tmax, A, start, tile_list, tile_n, tile_one, mesh_slot);
 }
 
 /* ================================================================== lattice noise (Texture.cpp:11-191) */

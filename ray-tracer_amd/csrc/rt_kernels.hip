@@ -903,7 +903,7 @@ __global__ void RT_LB_VISUAL(LITE, MODE) k_visual(const RtDevScene Sv, RtPipe P,
                 if (m != 255) { tile_list = P.tile_cand + (size_t)tile * RT_TILE_CAND; tile_n = m; }
             }
         }
-        int count = intersect_scene<LITE, CH_LDS, TILES, MESHPRE, SCHED>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one,
+        int count = trace_scene<LITE, CH_LDS, TILES, MESHPRE, SCHED>(S, lds, ray, RT_INFINITY, A, start, tile_list, tile_n, one,
                                                                   (LITE && MESHPRE) ? f - P.mx_f0 : ((!LITE && !direct) ? (P.mx_all ? f - P.mx_f0 : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
@@ -1855,7 +1855,7 @@ __global__ void RT_LB_SHADOW(LITE, MODE) k_shadow(const RtDevScene Sv, RtPipe P,
         ArenaT<false> A;
 #endif
         int start;
-        int count = intersect_scene<LITE, CH_LDS, false, MESHPRE, SCHED>(S, lds, ray, 1.0, A, start, 0, 0, -1,
+        int count = trace_scene<LITE, CH_LDS, false, MESHPRE, SCHED>(S, lds, ray, 1.0, A, start, 0, 0, -1,
                                                                   (LITE && MESHPRE) ? s : ((!LITE && !direct) ? (P.mx_all ? s : wbase + wlane) : -1));
         if (A.overflow) { atomicAdd(&P.counters[CTR_OVERFLOW], 1); atomicOr(&P.counters[CTR_OVERFLOW + 1], A.overflow); }
         bail = A.bail != 0;
