@@ -598,7 +598,7 @@ __global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
     }
 }
 
-/* workgroup sizes of the common (LITE) kernels: one workgroup per CU, 3 resp. 4 waves per SIMD, which also bounds
+/* workgroup sizes of the common (LITE) kernels: one workgroup per CU, three waves per SIMD, which also bounds
    their VGPRs (512 / waves per SIMD) */
 #ifdef RT_SMALL_BLOCKS      /* A/B variant: 256-thread workgroups, several per CU, the same waves per SIMD */
 #define RT_LITE_VISUAL_THREADS 256
@@ -612,7 +612,7 @@ __global__ void k_level_snap(RtPipe P, int level0, int gen_frames)
 #define RT_LITE_VISUAL_THREADS 768
 #endif
 #ifndef RT_LITE_SHADOW_THREADS
-#define RT_LITE_SHADOW_THREADS 1024
+#define RT_LITE_SHADOW_THREADS 768     /* (1024 = four waves per SIMD and 128 registers until round 3: S2 435 -> 411 ms, MESH10M 741 -> 730, S1 282 -> 279 with three and 168; 512: 436 / 739 / 295) */
 #endif
 #define RT_LITE_VISUAL_PER_CU  1
 #define RT_LITE_SHADOW_PER_CU  1
