@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(256) k_generate(const RtDevScene Sv, RtSampleG
    workgroup run times). */
 #define RT_GEN_ITERS 6
 #define RT_GEN_SPAN  (RT_GEN_ITERS * 256)
+static_assert(RT_GEN_SPAN <= RT_BLUE_N, "a generator workgroup's samples must lie in at most two sampling tiles (its early exit looks at the first and the last)");
 /* Survivors go one of two ways.  FAST: the sample's tile lists the children of the root region its rays can touch, and
    every child whose box the (approximate, conservative) ray touches is a bare chain of a two-root primitive without rare
    features (RtDevScene.root_fast): k_fast handles such a ray from (sample, chain) or (sample, touched entries of the
