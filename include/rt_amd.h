@@ -141,7 +141,7 @@ int  rt_probe_fast_time(rt_scene *s, double *out2);
    out3[0] = total ms, out3[1] = launches, out3[2] = rays walked. */
 int  rt_probe_mesh_time(rt_scene *s, double *out3);
 
-/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 33,552,000 = 20970 sampling tiles; the queues of a pass take about 2 KB of HBM per sample),
+/* Tunables (no counterpart in the reference).  name: "chunk_samples" (samples per wavefront pass, default 67,104,000 = 41940 sampling tiles, at most 2^26; the queues of a pass take about 2 KB of HBM per sample -- 134 GB at the default -- and a pass is made smaller when the device has less free),
    "bvh" (0/1: conservative culling boxes, union-region BVH and fused chains; takes effect at rt_scene_upload),
    "root_cull" (0/1: finish rays that miss every box of the scene in the generation kernel; at rt_scene_upload),
    "fuse_splat" (0/1/2, default 2: FastBlue reconstruction gathers the splats and filters rows in one kernel, the supersampled

@@ -247,7 +247,7 @@ class GpuScene:
 
 
 OPTION_NAMES = ("chunk_samples", "bvh", "root_cull", "lds_chains", "fuse_splat", "cell_order", "full_tables", "full_waves", "persistent",
-                "lds_tables", "tile_mask", "alt_chain", "tile_need", "tile_cand", "time_kernels", "fast_path", "fast_split", "cull_f32", "tile_aperture", "push_wrappers", "level_sync", "expect_empty", "rgb_sorted", "mesh_pre", "direct_full", "sched", "sort_rays", "pool_cache")
+                "lds_tables", "tile_mask", "alt_chain", "tile_need", "tile_cand", "time_kernels", "fast_path", "fast_split", "cull_f32", "tile_aperture", "push_wrappers", "level_sync", "expect_empty", "rgb_sorted", "mesh_pre", "direct_full", "sched", "sort_rays", "pool_cache", "level_copy", "matte_shape")
 
 
 def get_options():

@@ -274,7 +274,7 @@ def test_chunking_does_not_change_results(gpu, scene, chunk):
     becomes one tile) give the frame of the default pass size."""
     fs = gpu.FrontScene(scene, "fastblue", optimize=True)
     g = gpu.GpuScene(fs.desc)
-    assert gpu.get_options()["chunk_samples"] == 20970 * 1600 and gpu.get_options()["cell_order"] == 1
+    assert gpu.get_options()["chunk_samples"] == 41940 * 1600 and gpu.get_options()["cell_order"] == 1
     a, sa = g.render(96, 64, 4)
     gpu.set_options({"chunk_samples": chunk})
     b, sb = g.render(96, 64, 4)
@@ -298,7 +298,7 @@ def test_a_split_pass_leaves_later_renders_alone(gpu):
     rad = g.radiance(org, dr)
     gpu.set_options({"cell_order": 0})
     c, _ = g.render(96, 64, 4)
-    gpu.set_options({"cell_order": 1, "chunk_samples": 20970 * 1600})
+    gpu.set_options({"cell_order": 1, "chunk_samples": 41940 * 1600})
     again, sa = g.render(96, 64, 4)
     assert np.isfinite(rad).all() and np.array_equal(c, fresh)
     assert np.array_equal(again, fresh) and sa.rays() == sf.rays()
@@ -673,6 +673,29 @@ ONE_MESH = """(scene
  (camera perspective 0 0 6 40) (sampler fastblue))"""
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mesh", "row", "polished_row"])
+def test_matte_queue_shape_is_invisible(gpu, which):
+    """matte_shape: a scene without a polished surface never makes a child frame (k_shade spawns reflected / refracted rays at
+    polished boundaries alone, Shade.cpp:424-489), so its queues are one frame per root and one shadow slot per light -- an exact
+    bound, exercised here with passes of one sampling tile whose every root queues its shadow rays -- and its passes are three
+    times as large.  Frames and ray counts equal with the option off and on; a polished scene keeps the general shape either way."""
+    scene = {"mesh": ONE_MESH, "row": SCENE_ROW, "polished_row": SCENE_POLISHED_ROW}[which]
+    fs = gpu.FrontScene(scene, "fastblue", optimize=True)
+    assert gpu.get_options()["matte_shape"] == 1
+    out = []
+    try:
+        for on, chunk in ((0, 41940 * 1600), (1, 41940 * 1600), (1, 1600)):
+            gpu.set_options({"matte_shape": on, "chunk_samples": chunk})
+            img, st = gpu.GpuScene(fs.desc).render(200, 120, 4)
+            assert st.hit_overflow == 0 and st.rays_shadow > 0
+            out.append((img, (st.rays_primary, st.rays_shadow, st.rays_secondary)))
+    finally:
+        gpu.set_options({"matte_shape": 1, "chunk_samples": 41940 * 1600})
+    assert out[0][1] == out[1][1] == out[2][1] and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
+    assert (out[0][1][2] > 0) == (which == "polished_row")
+
+
 @pytest.mark.parametrize("wrap", ["plain", "glass"])
 def test_mesh_pre_walk_is_invisible(gpu, oracle, wrap):
     """k_mesh_cross (scenes with one mesh instruction: the rays the LITE kernels hand over are walked through the mesh's BVH
@@ -906,7 +929,7 @@ def test_single_candidate_shortcut_is_invisible(gpu):
 
 
 @pytest.mark.parametrize("name,off,on", [("lds_tables", 0, 1), ("lds_chains", 0, 1), ("full_waves", 1, 2), ("full_tables", 0, 1),
-                                         ("cell_order", 0, 1), ("persistent", 0, 1)])
+                                         ("cell_order", 0, 1), ("persistent", 0, 1), ("level_copy", 0, 1)])
 @pytest.mark.parametrize("scene", ["S0", "S1"])
 def test_launch_and_staging_options_are_invisible(gpu, scene, name, off, on):
     """The options that only choose where tables live, how kernels are launched or in which order samples are traced
