@@ -181,6 +181,11 @@ int  rt_probe_mesh_time(rt_scene *s, double *out3);
    at rt_scene_upload; results do not depend on it),
    "level_sync" (0/1, default 0: 1 makes every pass wait for the host after every level, also where the device-side
    bounds make that unnecessary; for A/B runs),
+   "level_copy" (0/1, default 1: the counters the host reads at the end of a level -- frames, shadow rays, what the common
+   kernels handed over -- come back in one copy into page-locked memory; 0: one copy per counter into pageable memory; for A/B runs),
+   "matte_shape" (0/1, default 1: a scene none of whose surfaces is polished never makes a reflected or refracted ray, so its
+   queues hold one frame per root sample and one shadow ray per light instead of four and two per light, and its passes are
+   three times chunk_samples unless its levels may be launched directly (direct_full), where smaller passes decide better; at rt_scene_upload; results do not depend on it),
    "mesh_pre" (0/1/2, default 2: scenes with exactly one mesh instruction walk their rays through the mesh's BVH in a kernel of
    its own, k_mesh_cross -- 1: the rays the common kernels hand over, before the kernels for the rare features run; 2: every ray
    of a level, before the common kernels, which then read the crossings themselves; 0: the walk inside the kernels for the rare
