@@ -177,7 +177,7 @@ def main():
 
     if rehearse and world > 2:
         # the ranks share ONE device's memory here, and each sizes its queue pool from what is free: smaller passes, so that all fit
-        rt.rt_lib().rt_set_option(b"chunk_samples", max(1 << 20, (1 << 25) // world))
+        rt.rt_lib().rt_set_option(b"chunk_samples", max(1 << 20, (1 << 26) // world))
     for kv in filter(None, args.opts.split(",")):
         name, val = kv.split("=")
         if rt.rt_lib().rt_set_option(name.encode(), int(val)):
